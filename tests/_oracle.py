@@ -1,0 +1,339 @@
+"""ctypes bindings for the CPU checkers (test infrastructure only).
+
+* ``Oracle``  -> oracle/liboracle.so, our restatement of the reference path.
+* ``Ref``     -> oracle/_ref/libref.so, the reference's own sources compiled by
+  oracle/Makefile.  Present in the build container (and shipped prebuilt to the
+  GPU box); tests that need it skip when it is missing.
+
+Both expose the same scene-building calls so one scene description can be
+instantiated in either.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+
+DIFFUSE, SPECULAR, MICROFACET = 0, 1, 2
+
+f32 = np.float32
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _vec(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_scene_spec():
+    """The scene hard-coded in the reference's src/main.cpp:7-84, as data."""
+    def v(*a):
+        return np.array(a, dtype=f32)
+    le = (f32(8.0) * v(f32(0.747) + f32(0.058), f32(0.747) + f32(0.258), f32(0.747))
+          + f32(15.6) * v(f32(0.740) + f32(0.287), f32(0.740) + f32(0.160), f32(0.740))
+          + f32(18.4) * v(f32(0.737) + f32(0.642), f32(0.737) + f32(0.159), f32(0.737)))
+    z = v(0, 0, 0)
+    d = 1e-5
+    mats = [
+        ("light", DIFFUSE, le, z, z, d, d),
+        ("white", DIFFUSE, z, v(.6, .6, .6), z, d, d),
+        ("red", DIFFUSE, z, v(.6, .01, .01), z, d, d),
+        ("green", DIFFUSE, z, v(.01, .6, .01), z, d, d),
+        ("blue", DIFFUSE, z, v(.01, .01, .6), z, d, d),
+        ("yellow", DIFFUSE, z, v(.6, .6, .01), z, d, d),
+        ("pink", DIFFUSE, z, v(.01, .6, .6), z, d, d),
+        ("cyan", DIFFUSE, z, v(.6, .01, .6), z, d, d),
+        ("spec", SPECULAR, z, v(1, 1, 1), z, d, d),
+        ("micro", MICROFACET, z, v(.6, .01, .01), v(.6, .01, .01), 0.0, 0.5),
+    ]
+    cube = np.array([[0, 0, -512], [512, 0, -512], [0, 512, -512], [512, 512, -512],
+                     [0, 0, 0], [512, 0, 0], [0, 512, 0], [512, 512, 0]], dtype=f32)
+    objs = [
+        ("sphere", "light", (256, 256, -256), 20),
+        ("mesh", "red", cube, [0, 1, 2, 3, 2, 1]),
+        ("mesh", "white", cube, [0, 4, 1, 5, 1, 4]),
+        ("mesh", "yellow", cube, [2, 3, 6, 7, 6, 3]),
+        ("mesh", "pink", cube, [0, 2, 4, 6, 4, 2]),
+        ("mesh", "cyan", cube, [1, 5, 3, 7, 3, 5]),
+        ("sphere", "red", (256, 512 - 64, -256), 32),
+        ("sphere", "blue", (64, 256, -256), 32),
+        ("sphere", "green", (512 - 64, 256, -256), 32),
+        ("sphere", "micro", (256, 64, -256), 32),
+        ("sphere", "spec", (64, 64, -512 + 64), 64),
+        ("sphere", "spec", (64, 512 - 64, -512 + 64), 64),
+        ("sphere", "spec", (512 - 64, 64, -512 + 64), 64),
+        ("sphere", "spec", (512 - 64, 512 - 64, -512 + 64), 64),
+    ]
+    cam = dict(pos=(256, 256, 512), front=(0, 0, -1), up=(0, 1, 0), fov=45.0)
+    return dict(materials=mats, objects=objs, camera=cam)
+
+
+class _Backend:
+    """Common scene-building front for liboracle.so / libref.so."""
+    prefix = None
+
+    def __init__(self, lib):
+        self.lib = lib
+        p = self.prefix
+        L = lib
+        getattr(L, p + "scene_new").restype = C.c_void_p
+        getattr(L, p + "scene_new").argtypes = [_fp, _fp, _fp, C.c_float]
+        getattr(L, p + "add_material").argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp,
+                                                   C.c_float, C.c_float]
+        getattr(L, p + "add_sphere").argtypes = [C.c_void_p, C.c_int, _fp, C.c_float]
+        getattr(L, p + "add_mesh").argtypes = [C.c_void_p, C.c_int, _fp, C.c_int, _up, C.c_int]
+        getattr(L, p + "build").argtypes = [C.c_void_p]
+        getattr(L, p + "flatten").argtypes = [C.c_void_p, _fp, _fp, _ip, _ip]
+        getattr(L, p + "top_leaf_order").argtypes = [C.c_void_p, _ip]
+        getattr(L, p + "object_area").argtypes = [C.c_void_p, C.c_int]
+        getattr(L, p + "object_area").restype = C.c_float
+        getattr(L, p + "intersect").argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
+        getattr(L, p + "slab").argtypes = [_fp, _fp, _fp, _fp]
+        getattr(L, p + "material_eval").argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]
+        getattr(L, p + "material_pdf").argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]
+
+    def build_scene(self, spec):
+        p = self.prefix
+        L = self.lib
+        cam = spec["camera"]
+        h = getattr(L, p + "scene_new")(_vec(cam["pos"]), _vec(cam["front"]), _vec(cam["up"]),
+                                        C.c_float(cam["fov"]))
+        ids = {}
+        for name, kind, e, kd, ks, ior, rough in spec["materials"]:
+            ids[name] = getattr(L, p + "add_material")(h, kind, _vec(e), _vec(kd), _vec(ks),
+                                                       C.c_float(ior), C.c_float(rough))
+        for ob in spec["objects"]:
+            if ob[0] == "sphere":
+                getattr(L, p + "add_sphere")(h, ids[ob[1]], _vec(ob[2]), C.c_float(ob[3]))
+            else:
+                pos = np.ascontiguousarray(ob[2], dtype=f32)
+                idx = np.ascontiguousarray(ob[3], dtype=np.uint32)
+                getattr(L, p + "add_mesh")(h, ids[ob[1]], _f(pos), len(pos),
+                                           idx.ctypes.data_as(_up), len(idx))
+        getattr(L, p + "build")(h)
+        return Scene(self, h, ids)
+
+
+class Scene:
+    def __init__(self, backend, handle, mat_ids):
+        self.b = backend
+        self.h = C.c_void_p(handle)
+        self.mat_ids = mat_ids
+
+    def _fn(self, name):
+        return getattr(self.b.lib, self.b.prefix + name)
+
+    def flatten(self):
+        n = self._fn("flatten")(self.h, None, None, None, None)
+        lo = np.zeros((n, 3), f32)
+        hi = np.zeros((n, 3), f32)
+        child = np.zeros((n, 2), np.int32)
+        prim = np.zeros(n, np.int32)
+        self._fn("flatten")(self.h, _f(lo), _f(hi), _i(child), _i(prim))
+        return lo, hi, child, prim
+
+    def top_leaf_order(self):
+        n = self._fn("top_leaf_order")(self.h, None)
+        out = np.zeros(n, np.int32)
+        self._fn("top_leaf_order")(self.h, _i(out))
+        return out
+
+    def object_area(self, o):
+        return f32(self._fn("object_area")(self.h, o))
+
+    def intersect(self, org, dirs):
+        org = np.ascontiguousarray(org, f32)
+        dirs = np.ascontiguousarray(dirs, f32)
+        n = len(org)
+        prim = np.zeros(n, np.int32)
+        t = np.zeros(n, f32)
+        pos = np.zeros((n, 3), f32)
+        nrm = np.zeros((n, 3), f32)
+        self._fn("intersect")(self.h, _f(org), _f(dirs), n, _i(prim), _f(t), _f(pos), _f(nrm))
+        return prim, t, pos, nrm
+
+    def material_eval(self, mat, wi, wo, n):
+        wi, wo, n = [np.ascontiguousarray(a, f32) for a in (wi, wo, n)]
+        out = np.zeros_like(wi)
+        self._fn("material_eval")(self.h, self.mat_ids[mat], _f(wi), _f(wo), _f(n), len(wi), _f(out))
+        return out
+
+    def material_pdf(self, mat, wi, wo, n):
+        wi, wo, n = [np.ascontiguousarray(a, f32) for a in (wi, wo, n)]
+        out = np.zeros(len(wi), f32)
+        self._fn("material_pdf")(self.h, self.mat_ids[mat], _f(wi), _f(wo), _f(n), len(wi), _f(out))
+        return out
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
+                ("seed", C.c_uint32), ("chunk_spp", C.c_int32), ("max_depth", C.c_int32),
+                ("rr_prob", C.c_float), ("threads", C.c_int32), ("recursive", C.c_int32),
+                ("col_begin", C.c_int32), ("col_end", C.c_int32)]
+
+
+class Oracle(_Backend):
+    prefix = "orc_"
+
+    def __init__(self):
+        lib = C.CDLL(ORACLE_SO)
+        super().__init__(lib)
+        L = lib
+        L.orc_default_scene.restype = C.c_void_p
+        L.orc_set_math.argtypes = [C.c_void_p, C.c_int]
+        L.orc_num_prims.argtypes = [C.c_void_p]
+        L.orc_material_sample.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]
+        L.orc_sample_light.argtypes = [C.c_void_p, _fp, C.c_int, _fp, _fp, _fp, _ip]
+        L.orc_path_trace_u.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int, _fp, _ip]
+        L.orc_philox4x32_10.argtypes = [_up, _up, _up]
+        L.orc_stream_uniform.argtypes = [C.c_uint32] * 5
+        L.orc_stream_uniform.restype = C.c_float
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), _fp,
+                                 C.POINTER(C.c_uint64)]
+        L.orc_primary_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]
+        L.orc_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+        L.orc_tonemap.argtypes = [C.c_float]
+        L.orc_tonemap.restype = C.c_ubyte
+
+    def default_scene(self):
+        ids = {m[0]: i for i, m in enumerate(default_scene_spec()["materials"])}
+        return Scene(self, self.lib.orc_default_scene(), ids)
+
+    def set_math(self, scene, portable):
+        self.lib.orc_set_math(scene.h, 1 if portable else 0)
+
+    def material_sample(self, scene, mat, wi, n, u2):
+        wi, n, u2 = [np.ascontiguousarray(a, f32) for a in (wi, n, u2)]
+        out = np.zeros_like(wi)
+        self.lib.orc_material_sample(scene.h, scene.mat_ids[mat], _f(wi), _f(n), _f(u2), len(wi),
+                                     _f(out))
+        return out
+
+    def sample_light(self, scene, u):
+        u = np.ascontiguousarray(u, f32)
+        pos = np.zeros(3, f32)
+        nrm = np.zeros(3, f32)
+        pdf = np.zeros(1, f32)
+        prim = np.zeros(1, np.int32)
+        used = self.lib.orc_sample_light(scene.h, _f(u), len(u), _f(pos), _f(nrm), _f(pdf), _i(prim))
+        return pos, nrm, pdf[0], int(prim[0]), used
+
+    def path_trace_u(self, scene, org, d, u):
+        u = np.ascontiguousarray(u, f32)
+        org = np.ascontiguousarray(org, f32)
+        d = np.ascontiguousarray(d, f32)
+        rgb = np.zeros(3, f32)
+        used = np.zeros(1, np.int32)
+        self.lib.orc_path_trace_u(scene.h, _f(org), _f(d), _f(u), len(u), _f(rgb), _i(used))
+        return rgb, int(used[0])
+
+    def philox(self, ctr, key):
+        c = np.array(ctr, np.uint32)
+        k = np.array(key, np.uint32)
+        o = np.zeros(4, np.uint32)
+        self.lib.orc_philox4x32_10(c.ctypes.data_as(_up), k.ctypes.data_as(_up),
+                                   o.ctypes.data_as(_up))
+        return o
+
+    def primary_ray(self, scene, W, H, i, j):
+        o = np.zeros(3, f32)
+        d = np.zeros(3, f32)
+        self.lib.orc_primary_ray(scene.h, W, H, i, j, _f(o), _f(d))
+        return o, d
+
+    def primary_rays(self, scene, W, H):
+        org = np.zeros((W * H, 3), f32)
+        d = np.zeros((W * H, 3), f32)
+        for i in range(W):
+            for j in range(H):
+                o1, d1 = self.primary_ray(scene, W, H, i, j)
+                org[i * H + j] = o1
+                d[i * H + j] = d1
+        return org, d
+
+    def render(self, scene, W, H, spp, seed=0, chunk_spp=0, max_depth=0, rr_prob=0.6, threads=0,
+               recursive=False, col_begin=0, col_end=0):
+        p = RenderParams(W, H, spp, seed, chunk_spp, max_depth, rr_prob, threads,
+                         1 if recursive else 0, col_begin, col_end)
+        rgb = np.zeros((W * H, 3), f32)
+        stats = (C.c_uint64 * 4)()
+        self.lib.orc_render(scene.h, C.byref(p), _f(rgb), stats)
+        return rgb, [int(x) for x in stats]
+
+    def counters(self, reset=True):
+        out = (C.c_uint64 * 4)()
+        self.lib.orc_counters(out, 1 if reset else 0)
+        return [int(x) for x in out]
+
+
+class Ref(_Backend):
+    prefix = "ref_"
+
+    def __init__(self):
+        lib = C.CDLL(REF_SO)
+        super().__init__(lib)
+        L = lib
+        L.ref_rng_seed.argtypes = [C.c_uint32]
+        L.ref_rng_draw.argtypes = [C.c_int, _fp]
+        L.ref_material_sample.argtypes = [C.c_void_p, C.c_int, _fp, _fp, C.c_uint32, C.c_int64, _fp]
+        L.ref_sample_light.argtypes = [C.c_void_p, C.c_uint32, _fp, _fp, _fp, _ip]
+        L.ref_path_trace.argtypes = [C.c_void_p, _fp, _fp, C.c_uint32, _fp]
+        L.ref_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, _fp]
+
+    def default_scene(self):
+        return self.build_scene(default_scene_spec())
+
+    def draws(self, seed, n):
+        out = np.zeros(n, f32)
+        self.lib.ref_rng_seed(seed)
+        self.lib.ref_rng_draw(n, _f(out))
+        return out
+
+    def material_sample(self, scene, mat, wi, n, seed):
+        wi, n = [np.ascontiguousarray(a, f32) for a in (wi, n)]
+        out = np.zeros_like(wi)
+        self.lib.ref_material_sample(scene.h, scene.mat_ids[mat], _f(wi), _f(n), seed, len(wi),
+                                     _f(out))
+        return out
+
+    def sample_light(self, scene, seed):
+        pos = np.zeros(3, f32)
+        nrm = np.zeros(3, f32)
+        pdf = np.zeros(1, f32)
+        prim = np.zeros(1, np.int32)
+        self.lib.ref_sample_light(scene.h, seed, _f(pos), _f(nrm), _f(pdf), _i(prim))
+        return pos, nrm, pdf[0], int(prim[0])
+
+    def path_trace(self, scene, org, d, seed):
+        org = np.ascontiguousarray(org, f32)
+        d = np.ascontiguousarray(d, f32)
+        rgb = np.zeros(3, f32)
+        self.lib.ref_path_trace(scene.h, _f(org), _f(d), seed, _f(rgb))
+        return rgb
+
+    def render(self, scene, W, H, spp, file="/tmp/ref_render"):
+        rgb = np.zeros((W * H, 3), f32)
+        rc = self.lib.ref_render(scene.h, W, H, spp, file.encode(), _f(rgb))
+        if rc != 0:
+            raise RuntimeError("reference render failed to open output file")
+        return rgb
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def have_oracle():
+    return os.path.exists(ORACLE_SO)
