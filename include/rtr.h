@@ -1,0 +1,230 @@
+/*
+ * rtr.h -- C ABI of the MI355X path-tracing library (librtr_hip.so).
+ *
+ * The reference renderer has no plugin or FFI seam: its path-tracing entry is
+ * the C++ method Render::renderPathTracing (include/Render.h:48,
+ * src/Render.cpp:632-694) fed by a Scene built from Material / Sphere /
+ * TrangleMesh objects (src/main.cpp:7-84).  This header is the boundary a
+ * binding for that path would use: the host layer (raytracingrenderer_amd/host)
+ * keeps the reference's classes, flattens the Scene it built into the plain
+ * arrays below and calls in here.  Everything behind these functions runs as
+ * hand-written HIP kernels for gfx950; there is no CPU fallback.
+ *
+ * Conventions: every function returns RTR_OK (0) or a negative RTR_ERR_* code
+ * and never throws; rtr_last_error() returns a thread-local message for the
+ * last failure on the calling thread.  Unless a parameter is documented as a
+ * device pointer, pointers are host memory owned by the caller, read or written
+ * only during the call.  A handle may be used from one thread at a time.
+ */
+#ifndef RTR_H
+#define RTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTR_OK 0
+#define RTR_ERR_INVALID (-1)     /* bad argument or malformed scene */
+#define RTR_ERR_DEVICE (-2)      /* HIP runtime error (message has the HIP string) */
+#define RTR_ERR_UNSUPPORTED (-3) /* valid request this build does not implement */
+#define RTR_ERR_NOMEM (-4)
+
+/* material kinds: enum MaterialType, include/Material.h:6-11 */
+#define RTR_DIFFUSE 0
+#define RTR_SPECULAR 1
+#define RTR_MICROFACET 2
+
+/* primitive kinds */
+#define RTR_PRIM_TRIANGLE 0 /* class Trangle, include/Trangle.h:7-47 */
+#define RTR_PRIM_SPHERE 1   /* class Sphere, include/Sphere.h:4-30 */
+
+typedef struct rtr_scene rtr_scene;
+
+/*
+ * A flattened Scene.  All arrays are structure-of-arrays; xyz triples are given
+ * as three separate pointers [0]=x [1]=y [2]=z.
+ *
+ * Tree: the reference's pointer BVH (struct BVHNode, include/BVH.h:9-22) with
+ * every TrangleMesh leaf replaced by that mesh's nested tree (whose root has the
+ * same bound, include/Trangle.h:56), numbered in any order.  A leaf has
+ * node_left == node_right == -1 and node_prim >= 0; an inner node has both
+ * children and node_prim == -1.  Child order matters: results of the two
+ * subtrees are merged with "strictly nearer keeps left, ties go right"
+ * (src/BVH.cpp:75-76).
+ *
+ * Primitives: prim ids are whatever the host assigns; the library reports hits
+ * by prim id.  prim_kind/prim_index select a row of the triangle or sphere
+ * arrays.  tri_n is the face normal the Trangle constructor stored
+ * (include/Trangle.h:28-33); areas are Trangle::area (twice the geometric
+ * area, include/Trangle.h:36-37) and Sphere::area (include/Sphere.h:20).
+ *
+ * Lights: Scene::lights order (include/Scene.h:37-42).  A sphere light is one
+ * prim; a mesh light lists its triangles' prim ids in the left-to-right leaf
+ * order of the mesh's own tree (the order BVH::getSample walks, src/BVH.cpp:82-95)
+ * in light_tris[light_tri_begin[l] .. light_tri_begin[l+1]).
+ */
+typedef struct rtr_scene_desc {
+  int32_t n_nodes;
+  int32_t root;
+  const float *node_bmin[3];
+  const float *node_bmax[3];
+  const int32_t *node_left;
+  const int32_t *node_right;
+  const int32_t *node_prim;
+
+  int32_t n_prims;
+  const int32_t *prim_kind;
+  const int32_t *prim_index;
+  const int32_t *prim_material;
+
+  int32_t n_tris;
+  const float *tri_p0[3];
+  const float *tri_p1[3];
+  const float *tri_p2[3];
+  const float *tri_n[3];
+  const float *tri_area;
+
+  int32_t n_spheres;
+  const float *sph_c[3];
+  const float *sph_r;
+  const float *sph_area;
+
+  int32_t n_materials;
+  const int32_t *mat_kind;
+  const float *mat_emission[3];
+  const float *mat_kd[3];
+  const float *mat_ks[3];
+  const float *mat_ior;       /* after the constructor's clamp, include/Material.h:58 */
+  const float *mat_roughness; /* after the constructor's clamp, include/Material.h:59 */
+
+  int32_t n_lights;
+  const int32_t *light_kind;      /* RTR_PRIM_SPHERE, or RTR_PRIM_TRIANGLE for a mesh */
+  const int32_t *light_prim;      /* sphere light: its prim id; mesh light: unused */
+  const float *light_area;        /* Object::getArea() of the light */
+  const int32_t *light_tri_begin; /* n_lights+1 offsets into light_tris */
+  const int32_t *light_tris;
+} rtr_scene_desc;
+
+/* struct Camera, include/Scene.h:6-20 */
+typedef struct rtr_camera {
+  float position[3];
+  float front[3];
+  float up[3];
+  float fov;
+} rtr_camera;
+
+/*
+ * Arguments of Render::renderPathTracing (include/Render.h:48) plus the knobs
+ * the reference hard-codes.  Zero means "the reference's value" for rr_prob
+ * (0.6f, src/Render.cpp:111,124) and max_depth (unbounded).
+ *
+ * Columns are partitioned for multi-GPU rendering: with part_count = R the
+ * image is cut into tiles of tile_cols columns and this call renders the tiles
+ * t with t % R == part_index; the output then holds only those columns, packed
+ * in increasing column order.  part_count <= 1 renders everything.
+ *
+ * Sample values do not depend on the partition, the pool size or the device:
+ * every uniform number is Philox4x32-10 of (pixel, sample, bounce, block) under
+ * key (seed, 0), pixel = i*height + j.
+ */
+typedef struct rtr_render_params {
+  int32_t width, height, spp;
+  uint32_t seed;
+  int32_t max_depth;  /* <=0: unbounded */
+  float rr_prob;      /* <=0: 0.6f */
+  int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: auto */
+  int32_t pool_size;  /* concurrent paths; <=0: auto */
+  int32_t part_index, part_count, tile_cols;
+  int32_t profile;    /* 1: time every kernel kind with events (slower) */
+} rtr_render_params;
+
+typedef struct rtr_stats {
+  uint64_t samples;        /* width*height*spp of the rendered columns */
+  uint64_t rays;           /* closest-hit queries actually traced */
+  uint64_t vertices;       /* path vertices shaded */
+  uint64_t iterations;     /* wavefront iterations */
+  int32_t chunk_spp, pool_size, n_columns, reserved;
+  double ms_total;         /* first launch -> framebuffer complete */
+  double ms_trace, ms_logic, ms_other; /* only with profile=1 */
+  uint64_t trace_launches; /* number of traversal-kernel launches */
+} rtr_stats;
+
+const char *rtr_last_error(void);
+int rtr_device_count(int *n);
+
+/* Uploads the scene to `device` (copies everything; the desc may be freed). */
+int rtr_scene_create(const rtr_scene_desc *desc, int device, rtr_scene **out);
+void rtr_scene_destroy(rtr_scene *scene);
+
+/*
+ * Closest hit for a batch of rays: Scene::intersect (include/Scene.h:46) ->
+ * BVH::intersect (src/BVH.cpp:66-80) -> Bound3::intersect (src/Bound3.cpp:3-22),
+ * Trangle::intersect (src/Trangle.cpp:3-28), Sphere::intersect
+ * (src/Sphere.cpp:3-39).  org_xyz/dir_xyz: n rows of x,y,z (directions need not
+ * be normalised).  prim_id[i] = -1 on a miss, else the prim id; t = Intersection::
+ * distance; pos_xyz / nrm_xyz (either may be NULL) = Intersection::postion /
+ * ::normal.  Results equal the reference's bit for bit.
+ */
+int rtr_trace_closest(rtr_scene *scene, const float *org_xyz, const float *dir_xyz, size_t n,
+                      int32_t *prim_id, float *t, float *pos_xyz, float *nrm_xyz);
+
+/* Same with DEVICE pointers on the scene's device; enqueues on `stream`
+ * (a hipStream_t, NULL = default stream) and returns without synchronising. */
+int rtr_trace_closest_device(rtr_scene *scene, const float *d_org_xyz, const float *d_dir_xyz,
+                             size_t n, int32_t *d_prim_id, float *d_t, float *d_pos_xyz,
+                             float *d_nrm_xyz, void *stream);
+
+/*
+ * Material::eval / Material::pdf / Material::sample (src/Material.cpp:66-168) on
+ * the device, one row per query.  u2: the two uniforms Material::sample would
+ * draw, in draw order (alph, theta).  Any output may be NULL.
+ */
+int rtr_material_eval(rtr_scene *scene, const int32_t *material, const float *wi_xyz,
+                      const float *wo_xyz, const float *n_xyz, size_t count, float *f_rgb,
+                      float *pdf);
+int rtr_material_sample(rtr_scene *scene, const int32_t *material, const float *wi_xyz,
+                        const float *n_xyz, const float *u2, size_t count, float *wo_xyz);
+
+/*
+ * Scene::samplingLight (src/Scene.cpp:16-35) on the device.  u: `stride`
+ * uniforms per query, consumed in the reference's draw order.  Outputs: sampled
+ * point, its normal, the pdf the reference returns, the prim id sampled (-1 if
+ * none) and the number of uniforms consumed.
+ */
+int rtr_sample_light(rtr_scene *scene, const float *u, int32_t stride, size_t count,
+                     float *pos_xyz, float *nrm_xyz, float *pdf, int32_t *prim_id,
+                     int32_t *n_used);
+
+/* The uniform number the renderer uses for (pixel, sample, bounce, dim). */
+int rtr_stream_uniform(rtr_scene *scene, uint32_t seed, const uint32_t *pixel,
+                       const uint32_t *sample, const uint32_t *bounce, const uint32_t *dim,
+                       size_t count, float *u);
+
+/*
+ * Render::renderPathTracing without the file write: the per-pixel sample loop
+ * (src/Render.cpp:651-665) over Render::pathTracing (src/Render.cpp:77-130) as
+ * a wavefront path tracer.  rgb_out: n_columns*height*3 floats, pixel (i,j) of
+ * the rendered columns at ((local column)*height + j)*3, i.e. the reference's
+ * buffer index i*height+j when nothing is partitioned.  stats may be NULL.
+ */
+int rtr_render_pt(rtr_scene *scene, const rtr_camera *camera, const rtr_render_params *params,
+                  float *rgb_out, rtr_stats *stats);
+
+/* Same, writing to a DEVICE buffer on the scene's device (for callers that keep
+ * the framebuffer in HBM, e.g. to gather it over RCCL).  Synchronises the
+ * scene's stream before returning. */
+int rtr_render_pt_device(rtr_scene *scene, const rtr_camera *camera,
+                         const rtr_render_params *params, float *d_rgb_out, rtr_stats *stats);
+
+/* Number of columns a partition renders (so callers can size buffers), and the
+ * global column index of each local column. */
+int rtr_partition_columns(int32_t width, int32_t part_index, int32_t part_count,
+                          int32_t tile_cols, int32_t *n_columns, int32_t *columns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,411 @@
+"""ctypes binding over librtr_host.so (scene building) and librtr_hip.so (C ABI).
+
+Every compute call goes ``HostScene`` -> ``rtr_*`` C ABI -> HIP kernels.  There
+is no fallback: a missing library or a failing device call raises ``RtrError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "librtr_hip.so")
+HOST_SO = os.path.join(_HERE, "librtr_host.so")
+
+DIFFUSE, SPECULAR, MICROFACET = 0, 1, 2
+
+f32 = np.float32
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+
+
+class RtrError(RuntimeError):
+    pass
+
+
+class RenderParams(C.Structure):
+    """rtr_render_params (include/rtr.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
+                ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_prob", C.c_float),
+                ("chunk_spp", C.c_int32), ("pool_size", C.c_int32),
+                ("part_index", C.c_int32), ("part_count", C.c_int32), ("tile_cols", C.c_int32),
+                ("profile", C.c_int32)]
+
+
+class Stats(C.Structure):
+    """rtr_stats (include/rtr.h)."""
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("vertices", C.c_uint64),
+                ("iterations", C.c_uint64), ("chunk_spp", C.c_int32), ("pool_size", C.c_int32),
+                ("n_columns", C.c_int32), ("reserved", C.c_int32), ("ms_total", C.c_double),
+                ("ms_trace", C.c_double), ("ms_logic", C.c_double), ("ms_other", C.c_double),
+                ("trace_launches", C.c_uint64)]
+
+
+class Camera(C.Structure):
+    """rtr_camera (include/rtr.h)."""
+    _fields_ = [("position", C.c_float * 3), ("front", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov", C.c_float)]
+
+
+# every symbol include/rtr.h declares
+ABI_SYMBOLS = [
+    "rtr_last_error", "rtr_device_count", "rtr_scene_create", "rtr_scene_destroy",
+    "rtr_trace_closest", "rtr_trace_closest_device", "rtr_material_eval", "rtr_material_sample",
+    "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
+    "rtr_partition_columns",
+]
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise RtrError("librtr_hip.so is not built; run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (there is no CPU fallback)")
+        L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        L.rtr_last_error.restype = C.c_char_p
+        L.rtr_device_count.argtypes = [_ip]
+        L.rtr_scene_destroy.argtypes = [C.c_void_p]
+        L.rtr_scene_destroy.restype = None
+        L.rtr_trace_closest.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t, _ip, _fp, _fp, _fp]
+        L.rtr_trace_closest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        L.rtr_material_eval.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp, _fp]
+        L.rtr_material_sample.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp]
+        L.rtr_sample_light.argtypes = [C.c_void_p, _fp, C.c_int32, C.c_size_t, _fp, _fp, _fp, _ip,
+                                       _ip]
+        L.rtr_stream_uniform.argtypes = [C.c_void_p, C.c_uint32, _up, _up, _up, _up, C.c_size_t, _fp]
+        L.rtr_render_pt.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), _fp,
+                                    C.POINTER(Stats)]
+        L.rtr_render_pt_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams),
+                                           C.c_void_p, C.POINTER(Stats)]
+        L.rtr_partition_columns.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(HOST_SO):
+            raise RtrError("librtr_host.so is not built; run __graft_entry__.build()")
+        L = C.CDLL(HOST_SO)
+        L.rtrh_last_error.restype = C.c_char_p
+        L.rtrh_scene_new.restype = C.c_void_p
+        L.rtrh_scene_new.argtypes = [_fp, _fp, _fp, C.c_float]
+        L.rtrh_scene_free.argtypes = [C.c_void_p]
+        L.rtrh_scene_free.restype = None
+        L.rtrh_add_material.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_float, C.c_float]
+        L.rtrh_add_sphere.argtypes = [C.c_void_p, C.c_int, _fp, C.c_float]
+        L.rtrh_add_mesh.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int, _up, C.c_int]
+        L.rtrh_build.argtypes = [C.c_void_p]
+        L.rtrh_flatten.argtypes = [C.c_void_p, _fp, _fp, _ip, _ip]
+        L.rtrh_num_prims.argtypes = [C.c_void_p]
+        L.rtrh_object_area.argtypes = [C.c_void_p, C.c_int]
+        L.rtrh_object_area.restype = C.c_float
+        L.rtrh_lights.argtypes = [C.c_void_p, _ip, _ip, _fp, _ip, _ip, _ip]
+        L.rtrh_set_device.argtypes = [C.c_void_p, C.c_int]
+        L.rtrh_device_scene.argtypes = [C.c_void_p]
+        L.rtrh_device_scene.restype = C.c_void_p
+        L.rtrh_material_id.argtypes = [C.c_void_p, C.c_int]
+        L.rtrh_intersect.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
+        L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
+                                  C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
+        _host = L
+    return _host
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _u(a):
+    return a.ctypes.data_as(_up)
+
+
+def _vec(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtrError("%s failed (%d): %s" % (what, rc, hip_lib().rtr_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = hip_lib().rtr_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def partition_columns(width, part_index, part_count, tile_cols=8):
+    n = C.c_int32(0)
+    _check(hip_lib().rtr_partition_columns(width, part_index, part_count, tile_cols, C.byref(n), None),
+           "rtr_partition_columns")
+    cols = np.zeros(n.value, np.int32)
+    _check(hip_lib().rtr_partition_columns(width, part_index, part_count, tile_cols, C.byref(n),
+                                           _i(cols)), "rtr_partition_columns")
+    return cols
+
+
+class HostScene:
+    """A scene built through the host library's mirror of the reference API."""
+
+    def __init__(self, camera):
+        self.L = host_lib()
+        self.cam = dict(camera)
+        self.h = C.c_void_p(self.L.rtrh_scene_new(_vec(camera["pos"]), _vec(camera["front"]),
+                                                  _vec(camera["up"]), C.c_float(camera["fov"])))
+        self.mat_ids = {}
+        self._dev = None
+
+    def close(self):
+        if self.h:
+            self.L.rtrh_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _herr(self, what):
+        raise RtrError("%s: %s" % (what, self.L.rtrh_last_error().decode()))
+
+    # ---- construction: Material / Sphere / TrangleMesh / Scene::addObject / rebuildBVH ----
+    def add_material(self, name, kind, emission=(0, 0, 0), kd=(0, 0, 0), ks=(0, 0, 0), ior=1e-5,
+                     roughness=1e-5):
+        self.mat_ids[name] = self.L.rtrh_add_material(self.h, kind, _vec(emission), _vec(kd),
+                                                      _vec(ks), C.c_float(ior), C.c_float(roughness))
+        return self.mat_ids[name]
+
+    def add_sphere(self, material, center, radius):
+        r = self.L.rtrh_add_sphere(self.h, self.mat_ids[material], _vec(center), C.c_float(radius))
+        if r < 0:
+            self._herr("add_sphere")
+        return r
+
+    def add_mesh(self, material, positions, indices):
+        pos = np.ascontiguousarray(positions, f32)
+        idx = np.ascontiguousarray(indices, np.uint32)
+        r = self.L.rtrh_add_mesh(self.h, self.mat_ids[material], _f(pos), len(pos), _u(idx), len(idx))
+        if r < 0:
+            self._herr("add_mesh")
+        return r
+
+    def build(self):
+        if self.L.rtrh_build(self.h) != 0:
+            self._herr("build")
+        self._dev = None
+
+    @classmethod
+    def from_spec(cls, spec):
+        s = cls(spec["camera"])
+        for name, kind, e, kd, ks, ior, rough in spec["materials"]:
+            s.add_material(name, kind, e, kd, ks, ior, rough)
+        for ob in spec["objects"]:
+            if ob[0] == "sphere":
+                s.add_sphere(ob[1], ob[2], ob[3])
+            else:
+                s.add_mesh(ob[1], ob[2], ob[3])
+        s.build()
+        return s
+
+    # ---- host-side introspection (no GPU) ----
+    def flatten(self):
+        n = self.L.rtrh_flatten(self.h, None, None, None, None)
+        if n < 0:
+            self._herr("flatten")
+        lo = np.zeros((n, 3), f32)
+        hi = np.zeros((n, 3), f32)
+        child = np.zeros((n, 2), np.int32)
+        prim = np.zeros(n, np.int32)
+        self.L.rtrh_flatten(self.h, _f(lo), _f(hi), _i(child), _i(prim))
+        return lo, hi, child, prim
+
+    def num_prims(self):
+        return self.L.rtrh_num_prims(self.h)
+
+    def object_area(self, o):
+        return f32(self.L.rtrh_object_area(self.h, o))
+
+    def lights(self):
+        n = self.L.rtrh_lights(self.h, None, None, None, None, None, None)
+        kind = np.zeros(n, np.int32)
+        prim = np.zeros(n, np.int32)
+        area = np.zeros(n, f32)
+        begin = np.zeros(n + 1, np.int32)
+        nt = C.c_int32(0)
+        self.L.rtrh_lights(self.h, _i(kind), _i(prim), _f(area), _i(begin), None, C.byref(nt))
+        tris = np.zeros(max(nt.value, 1), np.int32)
+        self.L.rtrh_lights(self.h, None, None, None, None, _i(tris), None)
+        return kind, prim, area, begin, tris[:nt.value]
+
+    def material_id(self, name):
+        return self.L.rtrh_material_id(self.h, self.mat_ids[name])
+
+    # ---- device: everything below calls the C ABI of include/rtr.h ----
+    def set_device(self, index):
+        self.L.rtrh_set_device(self.h, index)
+        self._dev = None
+
+    def device_scene(self):
+        if self._dev is None:
+            p = self.L.rtrh_device_scene(self.h)
+            if not p:
+                self._herr("device scene")
+            self._dev = C.c_void_p(p)
+        return self._dev
+
+    def intersect(self, org, dirs):
+        """rtr_trace_closest: (prim, t, pos, nrm)."""
+        org = np.ascontiguousarray(org, f32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, f32).reshape(-1, 3)
+        n = len(org)
+        prim = np.full(n, -1, np.int32)
+        t = np.zeros(n, f32)
+        pos = np.zeros((n, 3), f32)
+        nrm = np.zeros((n, 3), f32)
+        _check(hip_lib().rtr_trace_closest(self.device_scene(), _f(org), _f(dirs), n, _i(prim),
+                                           _f(t), _f(pos), _f(nrm)), "rtr_trace_closest")
+        return prim, t, pos, nrm
+
+    def material_eval(self, mat, wi, wo, n):
+        wi, wo, n = [np.ascontiguousarray(a, f32) for a in (wi, wo, n)]
+        ids = np.full(len(wi), self.material_id(mat), np.int32)
+        out = np.zeros_like(wi)
+        pdf = np.zeros(len(wi), f32)
+        _check(hip_lib().rtr_material_eval(self.device_scene(), _i(ids), _f(wi), _f(wo), _f(n),
+                                           len(wi), _f(out), _f(pdf)), "rtr_material_eval")
+        return out, pdf
+
+    def material_sample(self, mat, wi, n, u2):
+        wi, n, u2 = [np.ascontiguousarray(a, f32) for a in (wi, n, u2)]
+        ids = np.full(len(wi), self.material_id(mat), np.int32)
+        out = np.zeros_like(wi)
+        _check(hip_lib().rtr_material_sample(self.device_scene(), _i(ids), _f(wi), _f(n), _f(u2),
+                                             len(wi), _f(out)), "rtr_material_sample")
+        return out
+
+    def sample_light(self, u):
+        u = np.ascontiguousarray(u, f32)
+        n, stride = u.shape
+        pos = np.zeros((n, 3), f32)
+        nrm = np.zeros((n, 3), f32)
+        pdf = np.zeros(n, f32)
+        prim = np.zeros(n, np.int32)
+        used = np.zeros(n, np.int32)
+        _check(hip_lib().rtr_sample_light(self.device_scene(), _f(u), stride, n, _f(pos), _f(nrm),
+                                          _f(pdf), _i(prim), _i(used)), "rtr_sample_light")
+        return pos, nrm, pdf, prim, used
+
+    def stream_uniform(self, seed, pixel, sample, bounce, dim):
+        arrs = [np.ascontiguousarray(a, np.uint32) for a in (pixel, sample, bounce, dim)]
+        out = np.zeros(len(arrs[0]), f32)
+        _check(hip_lib().rtr_stream_uniform(self.device_scene(), seed, *[_u(a) for a in arrs],
+                                            len(out), _f(out)), "rtr_stream_uniform")
+        return out
+
+    def camera_struct(self):
+        c = Camera()
+        c.position[:] = [float(x) for x in self.cam["pos"]]
+        c.front[:] = [float(x) for x in self.cam["front"]]
+        c.up[:] = [float(x) for x in self.cam["up"]]
+        c.fov = float(self.cam["fov"])
+        return c
+
+    def make_params(self, W, H, spp, seed=0, max_depth=0, rr_prob=0.0, chunk_spp=0, pool_size=0,
+                    part_index=0, part_count=1, tile_cols=8, profile=False):
+        return RenderParams(W, H, spp, seed, max_depth, rr_prob, chunk_spp, pool_size, part_index,
+                            part_count, tile_cols, 1 if profile else 0)
+
+    def render(self, W, H, spp, **kw):
+        """rtr_render_pt into host memory: (rgb[n_cols*H,3], Stats)."""
+        p = self.make_params(W, H, spp, **kw)
+        ncol = len(partition_columns(W, p.part_index, p.part_count, p.tile_cols))
+        rgb = np.zeros((ncol * H, 3), f32)
+        st = Stats()
+        cam = self.camera_struct()
+        _check(hip_lib().rtr_render_pt(self.device_scene(), C.byref(cam), C.byref(p), _f(rgb),
+                                       C.byref(st)), "rtr_render_pt")
+        return rgb, st
+
+    def render_device(self, W, H, spp, d_ptr, **kw):
+        """rtr_render_pt_device into a device buffer (address as int)."""
+        p = self.make_params(W, H, spp, **kw)
+        st = Stats()
+        cam = self.camera_struct()
+        _check(hip_lib().rtr_render_pt_device(self.device_scene(), C.byref(cam), C.byref(p),
+                                              C.c_void_p(d_ptr), C.byref(st)),
+               "rtr_render_pt_device")
+        return st
+
+    def render_via_host_api(self, W, H, spp, file=None, **kw):
+        """Render::renderPathTracing of the host library (optionally writes file.ppm)."""
+        p = self.make_params(W, H, spp, **kw)
+        ncol = len(partition_columns(W, p.part_index, p.part_count, p.tile_cols))
+        rgb = np.zeros((ncol * H, 3), f32)
+        st = Stats()
+        rc = self.L.rtrh_render(self.h, W, H, spp, file.encode() if file else None, C.byref(p),
+                                _f(rgb), C.byref(st))
+        if rc != 0:
+            self._herr("render")
+        return rgb, st
+
+
+def default_scene_spec():
+    """The scene of the reference's src/main.cpp:7-84 as data (materials, objects, camera)."""
+    def v(*a):
+        return np.array(a, dtype=f32)
+    le = (f32(8.0) * v(f32(0.747) + f32(0.058), f32(0.747) + f32(0.258), f32(0.747))
+          + f32(15.6) * v(f32(0.740) + f32(0.287), f32(0.740) + f32(0.160), f32(0.740))
+          + f32(18.4) * v(f32(0.737) + f32(0.642), f32(0.737) + f32(0.159), f32(0.737)))
+    z = v(0, 0, 0)
+    d = 1e-5
+    mats = [
+        ("light", DIFFUSE, le, z, z, d, d),
+        ("white", DIFFUSE, z, v(.6, .6, .6), z, d, d),
+        ("red", DIFFUSE, z, v(.6, .01, .01), z, d, d),
+        ("green", DIFFUSE, z, v(.01, .6, .01), z, d, d),
+        ("blue", DIFFUSE, z, v(.01, .01, .6), z, d, d),
+        ("yellow", DIFFUSE, z, v(.6, .6, .01), z, d, d),
+        ("pink", DIFFUSE, z, v(.01, .6, .6), z, d, d),
+        ("cyan", DIFFUSE, z, v(.6, .01, .6), z, d, d),
+        ("spec", SPECULAR, z, v(1, 1, 1), z, d, d),
+        ("micro", MICROFACET, z, v(.6, .01, .01), v(.6, .01, .01), 0.0, 0.5),
+    ]
+    cube = np.array([[0, 0, -512], [512, 0, -512], [0, 512, -512], [512, 512, -512],
+                     [0, 0, 0], [512, 0, 0], [0, 512, 0], [512, 512, 0]], dtype=f32)
+    objs = [
+        ("sphere", "light", (256, 256, -256), 20),
+        ("mesh", "red", cube, [0, 1, 2, 3, 2, 1]),
+        ("mesh", "white", cube, [0, 4, 1, 5, 1, 4]),
+        ("mesh", "yellow", cube, [2, 3, 6, 7, 6, 3]),
+        ("mesh", "pink", cube, [0, 2, 4, 6, 4, 2]),
+        ("mesh", "cyan", cube, [1, 5, 3, 7, 3, 5]),
+        ("sphere", "red", (256, 512 - 64, -256), 32),
+        ("sphere", "blue", (64, 256, -256), 32),
+        ("sphere", "green", (512 - 64, 256, -256), 32),
+        ("sphere", "micro", (256, 64, -256), 32),
+        ("sphere", "spec", (64, 64, -512 + 64), 64),
+        ("sphere", "spec", (64, 512 - 64, -512 + 64), 64),
+        ("sphere", "spec", (512 - 64, 64, -512 + 64), 64),
+        ("sphere", "spec", (512 - 64, 512 - 64, -512 + 64), 64),
+    ]
+    cam = dict(pos=(256, 256, 512), front=(0, 0, -1), up=(0, 1, 0), fov=45.0)
+    return dict(materials=mats, objects=objs, camera=cam)
+
+
+def default_scene():
+    return HostScene.from_spec(default_scene_spec())

@@ -1,0 +1,719 @@
+// librtr_hip.so: the C ABI declared in include/rtr.h over the HIP kernels.
+// gfx950 only; there is no CPU implementation behind any of these entry points.
+#include "../../include/rtr.h"
+#include "rtr_kernels.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtr;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(RTR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *ptr = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct Workspace {
+  DevBuf<float4> pix_dir, pix_hit, pc_pos, pc_nrm, pc_wi, partial;
+  DevBuf<float4> pool[13];
+  DevBuf<uint32_t> shade_list, queue;
+  DevBuf<int32_t> cols;
+  DevBuf<float> rgb;
+  DevBuf<Counters> counters;
+  Counters *host_counters = nullptr;  // pinned
+  void release() {
+    pix_dir.release(); pix_hit.release(); pc_pos.release(); pc_nrm.release(); pc_wi.release();
+    partial.release();
+    for (auto &b : pool) b.release();
+    shade_list.release(); queue.release(); cols.release(); rgb.release(); counters.release();
+    if (host_counters) (void)hipHostFree(host_counters);
+    host_counters = nullptr;
+  }
+};
+
+}  // namespace
+
+struct rtr_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf<float4> nodes, tris, sphs, lights;
+  DevBuf<int32_t> tri_prim, sph_prim, prim_kind_row, prim_material, light_tris;
+  DevBuf<float> tri_area;
+  DevBuf<DeviceMaterial> mats;
+  DeviceScene ds{};
+  DeviceLights dl{};
+  int n_materials = 0;
+  Workspace ws;
+  // scratch for the host-pointer entry points
+  DevBuf<float> io_f[5];
+  DevBuf<int32_t> io_i[2];
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = 0;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (ok) (void)hipSetDevice(prev);
+  }
+};
+
+template <class T>
+int upload(DevBuf<T> &buf, const std::vector<T> &host) {
+  HIP_TRY(buf.reserve(host.size() ? host.size() : 1));
+  if (!host.empty())
+    HIP_TRY(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RTR_OK;
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// src/Render.cpp:639-649: the camera basis and per-pixel steps, in the
+// reference's mixed float/double arithmetic.
+CameraSetup camera_setup(const rtr_camera &c, int H) {
+  const double pi = 3.1415926;
+  auto v = [](const float *p) { return V3{p[0], p[1], p[2]}; };
+  V3 front = v(c.front), up = v(c.up);
+  V3 cr = V3{front.y * up.z - front.z * up.y, front.z * up.x - up.z * front.x,
+             front.x * up.y - front.y * up.x};
+  float len = sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+  V3 right = V3{cr.x / len, cr.y / len, cr.z / len};
+  double scale = (double)tanf((float)((double)c.fov / 2.0 / pi / 2.0)) * 2.0 / (double)(float)H;
+  float s = (float)scale;
+  CameraSetup cs;
+  cs.eye = v(c.position);
+  cs.front = front;
+  cs.vstep = V3{s * up.x, s * up.y, s * up.z};
+  cs.hstep = V3{s * right.x, s * right.y, s * right.z};
+  return cs;
+}
+
+void partition_columns(int W, int part_index, int part_count, int tile_cols,
+                       std::vector<int32_t> &cols) {
+  cols.clear();
+  if (part_count <= 1) {
+    for (int i = 0; i < W; i++) cols.push_back(i);
+    return;
+  }
+  if (tile_cols <= 0) tile_cols = 8;
+  for (int i = 0; i < W; i++)
+    if ((i / tile_cols) % part_count == part_index) cols.push_back(i);
+}
+
+int check_xyz(const float *const p[3], const char *name) {
+  if (!p[0] || !p[1] || !p[2]) return fail(RTR_ERR_INVALID, std::string(name) + " has a null axis");
+  return RTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtr_last_error(void) { return g_error.c_str(); }
+
+int rtr_device_count(int *n) {
+  if (!n) return fail(RTR_ERR_INVALID, "n is null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return fail(RTR_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *n = c;
+  return RTR_OK;
+}
+
+int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
+  if (!d || !out) return fail(RTR_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->n_nodes < 0 || d->n_prims < 0 || d->n_tris < 0 || d->n_spheres < 0 ||
+      d->n_materials < 0 || d->n_lights < 0)
+    return fail(RTR_ERR_INVALID, "negative count");
+  if (d->n_tris >= (1 << 30) || d->n_spheres >= (1 << 30))
+    return fail(RTR_ERR_INVALID, "too many primitives");
+  if (d->n_nodes > 0) {
+    if (int rc = check_xyz(d->node_bmin, "node_bmin")) return rc;
+    if (int rc = check_xyz(d->node_bmax, "node_bmax")) return rc;
+    if (!d->node_left || !d->node_right || !d->node_prim)
+      return fail(RTR_ERR_INVALID, "node links are null");
+    if (d->root < 0 || d->root >= d->n_nodes) return fail(RTR_ERR_INVALID, "root out of range");
+  }
+  if (d->n_prims > 0 && (!d->prim_kind || !d->prim_index || !d->prim_material))
+    return fail(RTR_ERR_INVALID, "prim arrays are null");
+  if (d->n_tris > 0) {
+    if (int rc = check_xyz(d->tri_p0, "tri_p0")) return rc;
+    if (int rc = check_xyz(d->tri_p1, "tri_p1")) return rc;
+    if (int rc = check_xyz(d->tri_p2, "tri_p2")) return rc;
+    if (int rc = check_xyz(d->tri_n, "tri_n")) return rc;
+    if (!d->tri_area) return fail(RTR_ERR_INVALID, "tri_area is null");
+  }
+  if (d->n_spheres > 0) {
+    if (int rc = check_xyz(d->sph_c, "sph_c")) return rc;
+    if (!d->sph_r || !d->sph_area) return fail(RTR_ERR_INVALID, "sphere arrays are null");
+  }
+  if (d->n_materials > 0) {
+    if (int rc = check_xyz(d->mat_emission, "mat_emission")) return rc;
+    if (int rc = check_xyz(d->mat_kd, "mat_kd")) return rc;
+    if (int rc = check_xyz(d->mat_ks, "mat_ks")) return rc;
+    if (!d->mat_kind || !d->mat_ior || !d->mat_roughness)
+      return fail(RTR_ERR_INVALID, "material arrays are null");
+  }
+  if (d->n_lights > 0 && (!d->light_kind || !d->light_prim || !d->light_area ||
+                          !d->light_tri_begin))
+    return fail(RTR_ERR_INVALID, "light arrays are null");
+
+  // ---- primitives ----
+  std::vector<int32_t> prim_kind_row(d->n_prims), prim_material(d->n_prims);
+  std::vector<int32_t> tri_prim(d->n_tris, -1), sph_prim(d->n_spheres, -1);
+  for (int p = 0; p < d->n_prims; p++) {
+    int kind = d->prim_kind[p], row = d->prim_index[p];
+    if (kind == RTR_PRIM_TRIANGLE) {
+      if (row < 0 || row >= d->n_tris) return fail(RTR_ERR_INVALID, "prim_index out of range");
+      tri_prim[row] = p;
+    } else if (kind == RTR_PRIM_SPHERE) {
+      if (row < 0 || row >= d->n_spheres) return fail(RTR_ERR_INVALID, "prim_index out of range");
+      sph_prim[row] = p;
+    } else {
+      return fail(RTR_ERR_INVALID, "unknown prim_kind");
+    }
+    prim_kind_row[p] = (kind << 30) | row;
+    int m = d->prim_material[p];
+    if (m < 0 || m >= d->n_materials) return fail(RTR_ERR_INVALID, "prim_material out of range");
+    prim_material[p] = m;
+  }
+
+  // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
+  std::vector<float4> nodes;
+  if (d->n_nodes > 0) {
+    const int n = d->n_nodes;
+    std::vector<int32_t> order;  // new index -> old index
+    std::vector<int32_t> depth_of;
+    std::vector<char> seen(n, 0);
+    std::vector<std::pair<int32_t, int32_t>> stack;  // (old node, depth)
+    stack.push_back({d->root, 1});
+    while (!stack.empty()) {
+      auto [o, dep] = stack.back();
+      stack.pop_back();
+      if (o < 0 || o >= n) return fail(RTR_ERR_INVALID, "child index out of range");
+      if (seen[o]) return fail(RTR_ERR_INVALID, "node reachable twice (not a tree)");
+      if (dep > kMaxDepth) return fail(RTR_ERR_INVALID, "tree deeper than 64 levels");
+      seen[o] = 1;
+      order.push_back(o);
+      depth_of.push_back(dep);
+      int l = d->node_left[o], r = d->node_right[o];
+      bool leaf = (l < 0 && r < 0);
+      if (leaf) {
+        int p = d->node_prim[o];
+        if (p < 0 || p >= d->n_prims) return fail(RTR_ERR_INVALID, "leaf without a valid prim");
+      } else {
+        if (l < 0 || r < 0) return fail(RTR_ERR_INVALID, "inner node with one child");
+        stack.push_back({r, dep + 1});
+        stack.push_back({l, dep + 1});  // left is visited first
+      }
+    }
+    if ((int)order.size() != n) return fail(RTR_ERR_INVALID, "unreachable nodes in the tree");
+    // skip[i] = first index after i's subtree = i + subtree size
+    std::vector<int32_t> size(n, 1);
+    for (int i = n - 1; i >= 0; i--) {
+      int o = order[i];
+      if (!(d->node_left[o] < 0 && d->node_right[o] < 0)) {
+        int li = i + 1;
+        int ri = li + size[li];
+        size[i] = 1 + size[li] + size[ri];
+      }
+    }
+    nodes.resize(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+      int o = order[i];
+      bool leaf = d->node_left[o] < 0 && d->node_right[o] < 0;
+      int32_t payload = leaf ? prim_kind_row[d->node_prim[o]] : -1;
+      int32_t skip = i + size[i];
+      float4 lo, hi;
+      lo.x = d->node_bmin[0][o]; lo.y = d->node_bmin[1][o]; lo.z = d->node_bmin[2][o];
+      hi.x = d->node_bmax[0][o]; hi.y = d->node_bmax[1][o]; hi.z = d->node_bmax[2][o];
+      memcpy(&lo.w, &skip, 4);
+      memcpy(&hi.w, &payload, 4);
+      nodes[2 * (size_t)i] = lo;
+      nodes[2 * (size_t)i + 1] = hi;
+    }
+  }
+
+  std::vector<float4> tris(3 * (size_t)d->n_tris), sphs(d->n_spheres);
+  std::vector<float> tri_area(d->n_tris);
+  for (int t = 0; t < d->n_tris; t++) {
+    tris[3 * (size_t)t] = make_float4(d->tri_p0[0][t], d->tri_p0[1][t], d->tri_p0[2][t], d->tri_n[0][t]);
+    tris[3 * (size_t)t + 1] = make_float4(d->tri_p1[0][t], d->tri_p1[1][t], d->tri_p1[2][t], d->tri_n[1][t]);
+    tris[3 * (size_t)t + 2] = make_float4(d->tri_p2[0][t], d->tri_p2[1][t], d->tri_p2[2][t], d->tri_n[2][t]);
+    tri_area[t] = d->tri_area[t];
+  }
+  for (int s = 0; s < d->n_spheres; s++)
+    sphs[s] = make_float4(d->sph_c[0][s], d->sph_c[1][s], d->sph_c[2][s], d->sph_r[s]);
+
+  std::vector<DeviceMaterial> mats(d->n_materials);
+  for (int m = 0; m < d->n_materials; m++) {
+    int kind = d->mat_kind[m];
+    if (kind < 0 || kind > 2) return fail(RTR_ERR_INVALID, "unknown material kind");
+    float ex = d->mat_emission[0][m], ey = d->mat_emission[1][m], ez = d->mat_emission[2][m];
+    // Material::hasEmission, include/Material.h:65 (float against a double literal)
+    bool emissive = (double)ex > 1e-4 || (double)ey > 1e-4 || (double)ez > 1e-4;
+    uint32_t tag = (uint32_t)kind | (emissive ? 0x100u : 0u);
+    float tagf;
+    memcpy(&tagf, &tag, 4);
+    mats[m].e_kind = make_float4(ex, ey, ez, tagf);
+    mats[m].kd_ior = make_float4(d->mat_kd[0][m], d->mat_kd[1][m], d->mat_kd[2][m], d->mat_ior[m]);
+    mats[m].ks_rough = make_float4(d->mat_ks[0][m], d->mat_ks[1][m], d->mat_ks[2][m], d->mat_roughness[m]);
+  }
+
+  // ---- lights ----
+  std::vector<float4> lights(d->n_lights);
+  std::vector<int32_t> light_tris;
+  float total_area = 0;
+  for (int l = 0; l < d->n_lights; l++) {
+    float4 rec;
+    rec.x = d->light_area[l];
+    total_area += d->light_area[l];  // fp32 running sum, src/Scene.cpp:17-20
+    int32_t kind = d->light_kind[l], z = 0, w = 0;
+    if (kind == RTR_PRIM_SPHERE) {
+      z = d->light_prim[l];
+      if (z < 0 || z >= d->n_prims || d->prim_kind[z] != RTR_PRIM_SPHERE)
+        return fail(RTR_ERR_INVALID, "sphere light does not name a sphere prim");
+    } else if (kind == RTR_PRIM_TRIANGLE) {
+      int b = d->light_tri_begin[l], e = d->light_tri_begin[l + 1];
+      if (b < 0 || e < b || (e > b && !d->light_tris))
+        return fail(RTR_ERR_INVALID, "bad light_tri_begin");
+      z = (int32_t)light_tris.size();
+      for (int k = b; k < e; k++) {
+        int p = d->light_tris[k];
+        if (p < 0 || p >= d->n_prims || d->prim_kind[p] != RTR_PRIM_TRIANGLE)
+          return fail(RTR_ERR_INVALID, "mesh light lists a non-triangle prim");
+        light_tris.push_back(d->prim_index[p]);
+      }
+      w = (int32_t)light_tris.size();
+    } else {
+      return fail(RTR_ERR_INVALID, "unknown light_kind");
+    }
+    memcpy(&rec.y, &kind, 4);
+    memcpy(&rec.z, &z, 4);
+    memcpy(&rec.w, &w, 4);
+    lights[l] = rec;
+  }
+
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RTR_ERR_INVALID, "device index out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(RTR_ERR_DEVICE, "hipSetDevice failed");
+
+  rtr_scene *s = new rtr_scene();
+  s->device = device;
+  auto bail = [&](int rc) {
+    rtr_scene_destroy(s);
+    return rc;
+  };
+  if (hipStreamCreate(&s->stream) != hipSuccess) {
+    s->stream = nullptr;
+    return bail(fail(RTR_ERR_DEVICE, "hipStreamCreate failed"));
+  }
+  int rc;
+  if ((rc = upload(s->nodes, nodes))) return bail(rc);
+  if ((rc = upload(s->tris, tris))) return bail(rc);
+  if ((rc = upload(s->sphs, sphs))) return bail(rc);
+  if ((rc = upload(s->tri_prim, tri_prim))) return bail(rc);
+  if ((rc = upload(s->sph_prim, sph_prim))) return bail(rc);
+  if ((rc = upload(s->prim_kind_row, prim_kind_row))) return bail(rc);
+  if ((rc = upload(s->prim_material, prim_material))) return bail(rc);
+  if ((rc = upload(s->mats, mats))) return bail(rc);
+  if ((rc = upload(s->lights, lights))) return bail(rc);
+  if ((rc = upload(s->light_tris, light_tris))) return bail(rc);
+  if ((rc = upload(s->tri_area, tri_area))) return bail(rc);
+  s->n_materials = d->n_materials;
+  s->ds.nodes = s->nodes.ptr;
+  s->ds.tris = s->tris.ptr;
+  s->ds.sphs = s->sphs.ptr;
+  s->ds.tri_prim = s->tri_prim.ptr;
+  s->ds.sph_prim = s->sph_prim.ptr;
+  s->ds.prim_kind_row = s->prim_kind_row.ptr;
+  s->ds.prim_material = s->prim_material.ptr;
+  s->ds.n_nodes = d->n_nodes;
+  s->ds.n_prims = d->n_prims;
+  s->dl.light = s->lights.ptr;
+  s->dl.light_tris = s->light_tris.ptr;
+  s->dl.tri_area = s->tri_area.ptr;
+  s->dl.n_lights = d->n_lights;
+  s->dl.total_area = total_area;
+  *out = s;
+  return RTR_OK;
+}
+
+void rtr_scene_destroy(rtr_scene *s) {
+  if (!s) return;
+  DeviceGuard guard(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  s->nodes.release(); s->tris.release(); s->sphs.release(); s->lights.release();
+  s->tri_prim.release(); s->sph_prim.release(); s->prim_kind_row.release();
+  s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
+  s->ws.release();
+  for (auto &b : s->io_f) b.release();
+  for (auto &b : s->io_i) b.release();
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_dir, size_t n,
+                             int32_t *d_prim, float *d_t, float *d_pos, float *d_nrm,
+                             void *stream) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n == 0) return RTR_OK;
+  if (!d_org || !d_dir || !d_prim || !d_t) return fail(RTR_ERR_INVALID, "null ray or result array");
+  if (n > (size_t)0x7fffffff * kBlock) return fail(RTR_ERR_INVALID, "batch too large");
+  DeviceGuard guard(s->device);
+  hipLaunchKernelGGL(k_trace_api, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, s->ds,
+                     d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
+  HIP_TRY(hipGetLastError());
+  return RTR_OK;
+}
+
+int rtr_trace_closest(rtr_scene *s, const float *org, const float *dir, size_t n, int32_t *prim,
+                      float *t, float *pos, float *nrm) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n == 0) return RTR_OK;
+  if (!org || !dir || !prim || !t) return fail(RTR_ERR_INVALID, "null ray or result array");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->io_f[0].reserve(3 * n));
+  HIP_TRY(s->io_f[1].reserve(3 * n));
+  HIP_TRY(s->io_f[2].reserve(n));
+  HIP_TRY(s->io_i[0].reserve(n));
+  if (pos) HIP_TRY(s->io_f[3].reserve(3 * n));
+  if (nrm) HIP_TRY(s->io_f[4].reserve(3 * n));
+  HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, org, 3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[1].ptr, dir, 3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  int rc = rtr_trace_closest_device(s, s->io_f[0].ptr, s->io_f[1].ptr, n, s->io_i[0].ptr,
+                                    s->io_f[2].ptr, pos ? s->io_f[3].ptr : nullptr,
+                                    nrm ? s->io_f[4].ptr : nullptr, s->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(prim, s->io_i[0].ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(t, s->io_f[2].ptr, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  if (pos) HIP_TRY(hipMemcpyAsync(pos, s->io_f[3].ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  if (nrm) HIP_TRY(hipMemcpyAsync(nrm, s->io_f[4].ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_material_eval(rtr_scene *s, const int32_t *material, const float *wi, const float *wo,
+                      const float *nn, size_t count, float *f, float *pdf) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (count == 0) return RTR_OK;
+  if (!material || !wi || !wo || !nn) return fail(RTR_ERR_INVALID, "null input array");
+  for (size_t i = 0; i < count; i++)
+    if (material[i] < 0 || material[i] >= s->n_materials)
+      return fail(RTR_ERR_INVALID, "material id out of range");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->io_i[0].reserve(count));
+  for (int k = 0; k < 4; k++) HIP_TRY(s->io_f[k].reserve(3 * count));
+  HIP_TRY(s->io_f[4].reserve(count));
+  HIP_TRY(hipMemcpyAsync(s->io_i[0].ptr, material, count * 4, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, wi, 12 * count, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[1].ptr, wo, 12 * count, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[2].ptr, nn, 12 * count, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_material_eval, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
+                     s->mats.ptr, s->io_i[0].ptr, s->io_f[0].ptr, s->io_f[1].ptr, s->io_f[2].ptr,
+                     count, s->io_f[3].ptr, s->io_f[4].ptr);
+  HIP_TRY(hipGetLastError());
+  if (f) HIP_TRY(hipMemcpyAsync(f, s->io_f[3].ptr, 12 * count, hipMemcpyDeviceToHost, s->stream));
+  if (pdf) HIP_TRY(hipMemcpyAsync(pdf, s->io_f[4].ptr, 4 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_material_sample(rtr_scene *s, const int32_t *material, const float *wi, const float *nn,
+                        const float *u2, size_t count, float *wo) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (count == 0) return RTR_OK;
+  if (!material || !wi || !nn || !u2 || !wo) return fail(RTR_ERR_INVALID, "null array");
+  for (size_t i = 0; i < count; i++)
+    if (material[i] < 0 || material[i] >= s->n_materials)
+      return fail(RTR_ERR_INVALID, "material id out of range");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->io_i[0].reserve(count));
+  for (int k = 0; k < 4; k++) HIP_TRY(s->io_f[k].reserve(3 * count));
+  HIP_TRY(hipMemcpyAsync(s->io_i[0].ptr, material, count * 4, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, wi, 12 * count, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[1].ptr, nn, 12 * count, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[2].ptr, u2, 8 * count, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_material_sample, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
+                     s->mats.ptr, s->io_i[0].ptr, s->io_f[0].ptr, s->io_f[1].ptr, s->io_f[2].ptr,
+                     count, s->io_f[3].ptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(wo, s->io_f[3].ptr, 12 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_sample_light(rtr_scene *s, const float *u, int32_t stride, size_t count, float *pos,
+                     float *nrm, float *pdf, int32_t *prim, int32_t *used) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (count == 0) return RTR_OK;
+  if (!u || stride <= 0 || !pos || !nrm || !pdf || !prim || !used)
+    return fail(RTR_ERR_INVALID, "null array or bad stride");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->io_f[0].reserve((size_t)stride * count));
+  HIP_TRY(s->io_f[1].reserve(3 * count));
+  HIP_TRY(s->io_f[2].reserve(3 * count));
+  HIP_TRY(s->io_f[3].reserve(count));
+  HIP_TRY(s->io_i[0].reserve(count));
+  HIP_TRY(s->io_i[1].reserve(count));
+  HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, u, 4 * (size_t)stride * count, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_sample_light, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, s->ds,
+                     s->dl, s->io_f[0].ptr, (int)stride, count, s->io_f[1].ptr, s->io_f[2].ptr,
+                     s->io_f[3].ptr, s->io_i[0].ptr, s->io_i[1].ptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pos, s->io_f[1].ptr, 12 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(nrm, s->io_f[2].ptr, 12 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(pdf, s->io_f[3].ptr, 4 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(prim, s->io_i[0].ptr, 4 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(used, s->io_i[1].ptr, 4 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_stream_uniform(rtr_scene *s, uint32_t seed, const uint32_t *pixel, const uint32_t *sample,
+                       const uint32_t *bounce, const uint32_t *dim, size_t count, float *u) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (count == 0) return RTR_OK;
+  if (!pixel || !sample || !bounce || !dim || !u) return fail(RTR_ERR_INVALID, "null array");
+  DeviceGuard guard(s->device);
+  for (int k = 0; k < 5; k++) HIP_TRY(s->io_f[k].reserve(count));
+  const uint32_t *src[4] = {pixel, sample, bounce, dim};
+  for (int k = 0; k < 4; k++)
+    HIP_TRY(hipMemcpyAsync(s->io_f[k].ptr, src[k], 4 * count, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_stream_uniform, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, seed,
+                     (const uint32_t *)s->io_f[0].ptr, (const uint32_t *)s->io_f[1].ptr,
+                     (const uint32_t *)s->io_f[2].ptr, (const uint32_t *)s->io_f[3].ptr, count,
+                     s->io_f[4].ptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(u, s->io_f[4].ptr, 4 * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_partition_columns(int32_t width, int32_t part_index, int32_t part_count,
+                          int32_t tile_cols, int32_t *n_columns, int32_t *columns) {
+  if (width < 0 || (part_count > 1 && (part_index < 0 || part_index >= part_count)))
+    return fail(RTR_ERR_INVALID, "bad partition");
+  std::vector<int32_t> cols;
+  partition_columns(width, part_index, part_count, tile_cols, cols);
+  if (n_columns) *n_columns = (int32_t)cols.size();
+  if (columns) memcpy(columns, cols.data(), cols.size() * sizeof(int32_t));
+  return RTR_OK;
+}
+
+int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm,
+                         float *d_rgb, rtr_stats *stats) {
+  if (!s || !cam || !prm || !d_rgb) return fail(RTR_ERR_INVALID, "null argument");
+  if (prm->width <= 0 || prm->height <= 0 || prm->spp <= 0)
+    return fail(RTR_ERR_INVALID, "width, height and spp must be positive");
+  if ((int64_t)prm->width * prm->height > 0x7fffffff)
+    return fail(RTR_ERR_INVALID, "image too large");
+  if (prm->part_count > 1 && (prm->part_index < 0 || prm->part_index >= prm->part_count))
+    return fail(RTR_ERR_INVALID, "part_index out of range");
+  auto t_start = std::chrono::steady_clock::now();
+  DeviceGuard guard(s->device);
+  Workspace &ws = s->ws;
+  hipStream_t st = s->stream;
+
+  std::vector<int32_t> cols;
+  partition_columns(prm->width, prm->part_index, prm->part_count, prm->tile_cols, cols);
+  RenderArgs a{};
+  a.W = prm->width; a.H = prm->height; a.spp = prm->spp;
+  a.n_cols = (int)cols.size();
+  a.n_pix = a.n_cols * a.H;
+  a.seed = prm->seed;
+  a.max_depth = prm->max_depth > 0 ? prm->max_depth : 0;
+  a.rr = prm->rr_prob > 0 ? prm->rr_prob : 0.6f;
+  a.chunk_spp = prm->chunk_spp > 0 ? prm->chunk_spp : (prm->spp + 63) / 64;
+  if (a.chunk_spp > a.spp) a.chunk_spp = a.spp;
+  a.n_chunks = (a.spp + a.chunk_spp - 1) / a.chunk_spp;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (a.n_pix == 0) return RTR_OK;
+  size_t max_units = (size_t)a.n_pix * a.n_chunks;
+  if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
+  size_t pool = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
+  if (pool > max_units) pool = max_units;
+  pool = (pool + kBlock - 1) / kBlock * kBlock;
+  if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
+  a.pool = (int)pool;
+  CameraSetup cs = camera_setup(*cam, a.H);
+
+  HIP_TRY(ws.cols.reserve(cols.size()));
+  HIP_TRY(ws.pix_dir.reserve(a.n_pix));
+  HIP_TRY(ws.pix_hit.reserve(a.n_pix));
+  HIP_TRY(ws.pc_pos.reserve(a.n_pix));
+  HIP_TRY(ws.pc_nrm.reserve(a.n_pix));
+  HIP_TRY(ws.pc_wi.reserve(a.n_pix));
+  HIP_TRY(ws.shade_list.reserve(a.n_pix));
+  HIP_TRY(ws.partial.reserve(max_units));
+  for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
+  HIP_TRY(ws.queue.reserve(2 * pool));
+  HIP_TRY(ws.counters.reserve(1));
+  if (!ws.host_counters) HIP_TRY(hipHostMalloc((void **)&ws.host_counters, sizeof(Counters)));
+
+  PixelCache pc{ws.pc_pos.ptr, ws.pc_nrm.ptr, ws.pc_wi.ptr};
+  PathPool pp{ws.pool[0].ptr, ws.pool[1].ptr, ws.pool[2].ptr, ws.pool[3].ptr, ws.pool[4].ptr,
+              ws.pool[5].ptr, ws.pool[6].ptr, ws.pool[7].ptr, ws.pool[8].ptr, ws.pool[9].ptr,
+              ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr};
+  Counters *cnt = ws.counters.ptr;
+
+  const bool prof = prm->profile != 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double ms_trace = 0, ms_logic = 0, ms_other = 0;
+  if (prof) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+  }
+  auto timed = [&](double &acc, auto &&launch) -> hipError_t {
+    if (prof) (void)hipEventRecord(ev0, st);
+    launch();
+    hipError_t e = hipGetLastError();
+    if (prof && e == hipSuccess) {
+      (void)hipEventRecord(ev1, st);
+      (void)hipEventSynchronize(ev1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev0, ev1);
+      acc += ms;
+    }
+    return e;
+  };
+
+  HIP_TRY(hipMemcpyAsync(ws.cols.ptr, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), st));
+  HIP_TRY(hipMemsetAsync(ws.pool[7].ptr, 0, pool * sizeof(float4), st));  // flags = 0: no unit
+  uint64_t trace_launches = 0;
+  HIP_TRY(timed(ms_other, [&] {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, cs,
+                       ws.cols.ptr, ws.pix_dir.ptr);
+  }));
+  HIP_TRY(timed(ms_trace, [&] {
+    hipLaunchKernelGGL(k_trace_primary, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, s->ds, cs,
+                       ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
+  }));
+  trace_launches++;
+  HIP_TRY(timed(ms_other, [&] {
+    hipLaunchKernelGGL(k_classify, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, s->ds,
+                       s->mats.ptr, cs, ws.pix_dir.ptr, ws.pix_hit.ptr, pc, ws.shade_list.ptr, cnt,
+                       ws.partial.ptr);
+  }));
+  HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
+
+  uint64_t iters = 0;
+  if (n_units > 0) {
+    const int batch = 16;
+    for (;;) {
+      for (int b = 0; b < batch; b++) {
+        int parity = (int)(iters & 1);
+        HIP_TRY(timed(ms_logic, [&] {
+          hipLaunchKernelGGL(k_logic, dim3(blocks_for(pool)), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                             s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, cnt,
+                             ws.partial.ptr, parity);
+        }));
+        HIP_TRY(timed(ms_trace, [&] {
+          hipLaunchKernelGGL(k_trace_queue, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st, s->ds,
+                             pp, ws.queue.ptr, cnt, parity);
+        }));
+        trace_launches++;
+        iters++;
+      }
+      HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (ws.host_counters->units_done >= n_units) break;
+      if (iters > (uint64_t)1 << 40) return fail(RTR_ERR_DEVICE, "render did not terminate");
+    }
+  }
+  HIP_TRY(timed(ms_other, [&] {
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a,
+                       ws.partial.ptr, d_rgb);
+  }));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (prof) {
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
+  if (stats) {
+    stats->samples = (uint64_t)a.n_pix * a.spp;
+    stats->rays = ws.host_counters->rays + (uint64_t)a.n_pix;
+    stats->vertices = ws.host_counters->vertices;
+    stats->iterations = iters;
+    stats->chunk_spp = a.chunk_spp;
+    stats->pool_size = a.pool;
+    stats->n_columns = a.n_cols;
+    stats->ms_trace = ms_trace;
+    stats->ms_logic = ms_logic;
+    stats->ms_other = ms_other;
+    stats->trace_launches = trace_launches;
+    stats->ms_total =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  }
+  return RTR_OK;
+}
+
+int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm, float *rgb,
+                  rtr_stats *stats) {
+  if (!s || !cam || !prm || !rgb) return fail(RTR_ERR_INVALID, "null argument");
+  if (prm->width <= 0 || prm->height <= 0) return fail(RTR_ERR_INVALID, "bad image size");
+  auto t_start = std::chrono::steady_clock::now();
+  std::vector<int32_t> cols;
+  partition_columns(prm->width, prm->part_index, prm->part_count, prm->tile_cols, cols);
+  size_t n = (size_t)cols.size() * prm->height * 3;
+  if (n == 0) return RTR_OK;
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->ws.rgb.reserve(n));
+  int rc = rtr_render_pt_device(s, cam, prm, s->ws.rgb.ptr, stats);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(rgb, s->ws.rgb.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (stats)
+    stats->ms_total =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return RTR_OK;
+}
+
+} /* extern "C" */

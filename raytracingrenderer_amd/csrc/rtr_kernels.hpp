@@ -1,0 +1,451 @@
+// The wavefront path tracer's kernels (gfx950, wave64).
+//
+// One render = ray generation -> primary trace -> classify, then a loop of
+//   pt_logic  (consume last iteration's hits, Russian roulette result, path
+//              regeneration, light sampling, BSDF sampling, ray emission with
+//              64-wide ballot compaction into the ray queue)
+//   pt_trace  (closest hit for every queued ray)
+// and a final resolve.  Path state lives in HBM as float4 structure-of-arrays
+// indexed by slot; a slot keeps one path and moves on to the next sample of its
+// work unit when the path ends, so lanes stay busy while samples remain.
+//
+// A work unit is (pixel, chunk of consecutive samples).  A slot sums its unit's
+// samples in order in registers/state and writes ONE partial sum per unit, so
+// the image needs no atomics and is bit-reproducible: it does not depend on the
+// pool size, the scheduling order or how columns are split across GPUs.
+#pragma once
+#include "rtr_shade.hpp"
+
+namespace rtr {
+
+constexpr int kBlock = 256;
+
+struct CameraSetup {  // src/Render.cpp:639-649, computed on the host
+  V3 eye, front, hstep, vstep;
+};
+
+struct PixelCache {  // first path vertex of every pixel: identical for all its samples
+  float4 *pos_mat;   // pos.xyz, bits(material)      (material = -1: miss, -2: emissive)
+  float4 *nrm;       // unit normal
+  float4 *wi;        // -unit(primary dir), w = bits(global pixel id i*H+j)
+};
+
+struct PathPool {
+  float4 *A;   // vertex pos.xyz, bits(material)
+  float4 *B;   // unit normal N.xyz, bits(depth)
+  float4 *C;   // wi.xyz, bits(local pixel)
+  float4 *D;   // beta.xyz, bits(sample k)
+  float4 *E;   // L.xyz (radiance of the current path), bits(k_end)
+  float4 *F;   // acc.xyz (sum over the unit's finished samples), bits(chunk)
+  float4 *G;   // pending next-event weight Le*f*cos*cos, light pdf
+  float4 *Hh;  // light point.xyz, bits(flags)
+  float4 *I;   // beta after the pending bounce, bits(global pixel id)
+  float4 *J;   // shadow ray direction
+  float4 *K;   // extension ray direction
+  float4 *hs;  // shadow hit  {t, b1, b2, bits(leaf)}
+  float4 *he;  // extension hit
+};
+
+enum : uint32_t { kLive = 1u, kHasShadow = 2u, kHasExt = 4u, kHasUnit = 8u };
+
+struct Counters {
+  unsigned int qcount[2];
+  unsigned int next_unit;
+  unsigned int units_done;
+  unsigned int n_shade;
+  unsigned int pad;
+  unsigned long long rays;
+  unsigned long long vertices;
+};
+
+struct RenderArgs {
+  int32_t W, H, spp, n_cols, n_pix;  // n_pix = n_cols * H (local pixels)
+  uint32_t seed;
+  int32_t max_depth;
+  float rr;
+  int32_t chunk_spp, n_chunks, pool;
+};
+
+RTR_DEV unsigned lane_id() { return threadIdx.x & 63u; }
+RTR_DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
+
+// ---- ray generation: src/Render.cpp:654 ----
+__global__ void __launch_bounds__(kBlock)
+k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4 *__restrict__ dir) {
+  int lp = blockIdx.x * kBlock + threadIdx.x;
+  if (lp >= a.n_pix) return;
+  int lc = lp / a.H, j = lp - lc * a.H;
+  int i = cols[lc];
+  V3 d = unit(cam.front + (float)(-a.W / 2 + i) * cam.hstep + (float)(-a.H / 2 + j) * cam.vstep);
+  dir[lp] = pack(d, (uint32_t)(i * a.H + j));
+}
+
+// ---- traversal over explicit ray arrays (the rtr_trace_closest entry point) ----
+__global__ void __launch_bounds__(kBlock)
+k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
+            int32_t *__restrict__ prim, float *__restrict__ t, float *__restrict__ pos,
+            float *__restrict__ nrm) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+  V3 d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  V3 dn = unit(d);
+  HitRec h = trace_closest(sc, o, d, dn);
+  prim[i] = hit_prim(sc, h);
+  t[i] = h.t;
+  V3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+  if (h.leaf >= 0) hit_point(sc, h, o, dn, p, nn);
+  if (pos) { pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z; }
+  if (nrm) { nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z; }
+}
+
+// ---- traversal of the primary rays (one per pixel, shared by all its samples) ----
+__global__ void __launch_bounds__(kBlock)
+k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir, int n,
+                float4 *__restrict__ hit) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 d = xyz(dir[i]);
+  HitRec h = trace_closest(sc, cam.eye, d, unit(d));
+  hit[i] = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
+}
+
+// ---- traversal of the ray queue ----
+__global__ void __launch_bounds__(kBlock)
+k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
+              const Counters *__restrict__ cnt, int parity) {
+  unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cnt->qcount[parity]) return;
+  uint32_t e = queue[i];
+  uint32_t slot = e & 0x7fffffffu;
+  bool ext = e >> 31;
+  V3 o = xyz(p.A[slot]);
+  V3 d = xyz(ext ? p.K[slot] : p.J[slot]);
+  HitRec h = trace_closest(sc, o, d, unit(d));
+  float4 out = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
+  if (ext) p.he[slot] = out; else p.hs[slot] = out;
+}
+
+// ---- first vertex of every pixel; pixels that need no sampling are finished here ----
+__global__ void __launch_bounds__(kBlock)
+k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats, CameraSetup cam,
+           const float4 *__restrict__ dir, const float4 *__restrict__ hit, PixelCache pc,
+           uint32_t *__restrict__ shade_list, Counters *__restrict__ cnt,
+           float4 *__restrict__ partial) {
+  int lp = blockIdx.x * kBlock + threadIdx.x;
+  bool shade = false;
+  if (lp < a.n_pix) {
+    float4 dv = dir[lp];
+    float4 hv = hit[lp];
+    HitRec h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+    V3 d = xyz(dv);
+    V3 dn = unit(d);
+    V3 value = mk(0, 0, 0);
+    int mat = -1;
+    if (h.leaf >= 0) {
+      V3 pos, nn;
+      hit_point(sc, h, cam.eye, dn, pos, nn);
+      int m = sc.prim_material[hit_prim(sc, h)];
+      DeviceMaterial dm = mats[m];
+      if (mat_emissive(dm)) {
+        mat = -2;
+        value = xyz(dm.e_kind);
+      } else {
+        mat = m;
+        shade = true;
+        pc.nrm[lp] = pack(unit(nn), 0.0f);
+      }
+      pc.pos_mat[lp] = pack(pos, (uint32_t)mat);
+    } else {
+      pc.pos_mat[lp] = pack(mk(0, 0, 0), (uint32_t)mat);
+    }
+    pc.wi[lp] = pack(-dn, wbits(dv));
+    if (!shade) {
+      // every sample of this pixel returns `value` (src/Render.cpp:84-87); the
+      // sums are still formed by repeated addition like the reference's loop
+      for (int c = 0; c < a.n_chunks; c++) {
+        int k0 = c * a.chunk_spp, k1 = min(a.spp, k0 + a.chunk_spp);
+        V3 acc = mk(0, 0, 0);
+        for (int k = k0; k < k1; k++) acc = acc + value;
+        partial[(size_t)c * a.n_pix + lp] = pack(acc, 0.0f);
+      }
+    }
+  }
+  unsigned long long m = __ballot(shade);
+  if (m) {
+    unsigned base = 0;
+    int leader = __ffsll((long long)m) - 1;
+    if ((int)lane_id() == leader) base = atomicAdd(&cnt->n_shade, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (shade) shade_list[base + __popcll(m & lanes_below())] = (uint32_t)lp;
+  }
+}
+
+// ---- one wavefront iteration of path logic ----
+__global__ void __launch_bounds__(kBlock)
+k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
+        PixelCache pc, PathPool p, const uint32_t *__restrict__ shade_list,
+        uint32_t *__restrict__ queue, Counters *__restrict__ cnt, float4 *__restrict__ partial,
+        int parity) {
+  const int slot = blockIdx.x * kBlock + threadIdx.x;
+  const bool in_range = slot < a.pool;
+  if (slot == 0) cnt->qcount[parity ^ 1] = 0;
+
+  uint32_t flags = 0;
+  V3 pos = mk(0, 0, 0), N = pos, wi = pos, beta = pos, Lp = pos, acc = pos;
+  uint32_t mat = 0, depth = 0, lp = 0, k = 0, k_end = 0, chunk = 0, gpix = 0;
+  if (in_range) {
+    float4 h4 = p.Hh[slot];
+    flags = wbits(h4);
+    if (flags & kHasUnit) {
+      float4 a4 = p.A[slot], b4 = p.B[slot], c4 = p.C[slot], d4 = p.D[slot], e4 = p.E[slot],
+             f4 = p.F[slot];
+      pos = xyz(a4); mat = wbits(a4);
+      N = xyz(b4); depth = wbits(b4);
+      wi = xyz(c4); lp = wbits(c4);
+      beta = xyz(d4); k = wbits(d4);
+      Lp = xyz(e4); k_end = wbits(e4);
+      acc = xyz(f4); chunk = wbits(f4);
+      gpix = wbits(p.I[slot]);
+    }
+    if (flags & kLive) {
+      // next-event result: src/Render.cpp:95-107
+      if (flags & kHasShadow) {
+        float4 hv = p.hs[slot];
+        HitRec h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+        if (h.leaf >= 0) {
+          V3 hp, hn;
+          hit_point(sc, h, pos, unit(xyz(p.J[slot])), hp, hn);
+          float4 g4 = p.G[slot];
+          float dl = length(hp - xyz(h4));
+          if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
+            V3 term = xyz(g4) / (h.t * h.t) / g4.w;
+            Lp = Lp + beta * term;
+          }
+        }
+      }
+      // extension result: src/Render.cpp:117-125
+      bool cont = false;
+      if (flags & kHasExt) {
+        float4 hv = p.he[slot];
+        HitRec h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+        if (h.leaf >= 0) {
+          int m2 = sc.prim_material[hit_prim(sc, h)];
+          if (!mat_emissive(mats[m2]) && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
+            V3 w1 = xyz(p.K[slot]);
+            V3 dn = unit(w1);
+            V3 hp, hn;
+            hit_point(sc, h, pos, dn, hp, hn);
+            beta = xyz(p.I[slot]);
+            wi = -dn;
+            N = unit(hn);
+            pos = hp;
+            mat = (uint32_t)m2;
+            depth++;
+            cont = true;
+          }
+        }
+      }
+      if (!cont) {
+        acc = acc + Lp;  // color = color + pathTracing(...), src/Render.cpp:659
+        k++;
+        flags &= ~kLive;
+      }
+    }
+  }
+
+  // a slot without a live path starts the next sample of its unit, or a new unit
+  bool unit_finished = in_range && (flags & kHasUnit) && !(flags & kLive) && k >= k_end;
+  if (unit_finished) {
+    partial[(size_t)chunk * a.n_pix + lp] = pack(acc, 0.0f);
+    flags &= ~kHasUnit;
+  }
+  bool want_unit = in_range && !(flags & kHasUnit);
+  const unsigned n_units = cnt->n_shade * (unsigned)a.n_chunks;
+  {
+    unsigned long long m_fin = __ballot(unit_finished);
+    unsigned long long m_want = __ballot(want_unit);
+    if (m_fin | m_want) {
+      int leader = __ffsll((long long)(m_fin | m_want)) - 1;
+      unsigned base = n_units;
+      if ((int)lane_id() == leader) {
+        if (m_fin) atomicAdd(&cnt->units_done, (unsigned)__popcll(m_fin));
+        if (m_want && *(volatile unsigned *)&cnt->next_unit < n_units)
+          base = atomicAdd(&cnt->next_unit, (unsigned)__popcll(m_want));
+      }
+      base = __shfl(base, leader);
+      if (want_unit) {
+        unsigned u = base + (unsigned)__popcll(m_want & lanes_below());
+        if (base < n_units && u < n_units) {
+          unsigned ns = cnt->n_shade;
+          chunk = u / ns;
+          lp = shade_list[u - chunk * ns];
+          k = chunk * (uint32_t)a.chunk_spp;
+          k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+          acc = mk(0, 0, 0);
+          gpix = wbits(pc.wi[lp]);
+          flags |= kHasUnit;
+        }
+      }
+    }
+  }
+  bool live = in_range && (flags & kHasUnit);
+  if (live && !(flags & kLive)) {
+    // new sample: every sample of a pixel starts at the same first vertex
+    float4 pm = pc.pos_mat[lp];
+    pos = xyz(pm); mat = wbits(pm);
+    N = xyz(pc.nrm[lp]);
+    wi = xyz(pc.wi[lp]);
+    beta = mk(1, 1, 1);
+    Lp = mk(0, 0, 0);
+    depth = 0;
+    flags |= kLive;
+  }
+
+  // shade the current vertex: src/Render.cpp:90-116
+  bool has_shadow = false, has_ext = false;
+  if (live) {
+    DeviceMaterial dm = mats[mat];
+    VertexStream rng(a.seed, gpix, k, depth);
+    LightSample ls;
+    sample_light(sc, L, rng, ls);
+    if (ls.pdf > 0) {
+      V3 l = unit(ls.pos - pos);
+      V3 l2 = unit(l);
+      int lprim = (ls.leaf >> 30) ? sc.sph_prim[ls.leaf & 0x3fffffff] : sc.tri_prim[ls.leaf];
+      V3 Le = xyz(mats[sc.prim_material[lprim]].e_kind);
+      V3 w = Le * mat_eval(dm, wi, l2, N) * dot(N, l2) * dot(unit(ls.nrm), -l2);
+      p.G[slot] = pack(w, ls.pdf);
+      p.J[slot] = pack(l, 0.0f);
+      has_shadow = true;
+    }
+    if (rng.next() < a.rr) {
+      V3 wo;
+      if (mat_kind(dm) == 1) {
+        wo = mat_mirror(wi, N);
+      } else {
+        float u1 = rng.next();
+        float u2 = rng.next();
+        wo = mat_sample_uv(N, u1, u2);
+      }
+      float pdf = mat_pdf(dm);
+      V3 w1 = unit(wo);
+      V3 bn = beta * mat_eval(dm, wi, unit(w1), N) * dot(N, w1) / pdf / a.rr;
+      p.I[slot] = pack(bn, gpix);
+      p.K[slot] = pack(w1, 0.0f);
+      has_ext = true;
+    } else {
+      p.I[slot] = pack(mk(0, 0, 0), gpix);
+    }
+    flags = (flags & ~(kHasShadow | kHasExt)) | (has_shadow ? kHasShadow : 0u) |
+            (has_ext ? kHasExt : 0u);
+    p.A[slot] = pack(pos, mat);
+    p.B[slot] = pack(N, depth);
+    p.C[slot] = pack(wi, lp);
+    p.D[slot] = pack(beta, k);
+    p.E[slot] = pack(Lp, k_end);
+    p.F[slot] = pack(acc, chunk);
+    p.Hh[slot] = pack(ls.pos, flags);
+  } else if (in_range) {
+    p.Hh[slot] = pack(mk(0, 0, 0), 0u);
+  }
+
+  // 64-wide compaction of the emitted rays into the queue
+  unsigned long long ms = __ballot(has_shadow), me = __ballot(has_ext), ml = __ballot(live);
+  if (ml) {
+    int leader = __ffsll((long long)ml) - 1;
+    unsigned ns = (unsigned)__popcll(ms), ne = (unsigned)__popcll(me);
+    unsigned base = 0;
+    if ((int)lane_id() == leader) {
+      base = atomicAdd(&cnt->qcount[parity], ns + ne);
+      atomicAdd(&cnt->rays, (unsigned long long)(ns + ne));
+      atomicAdd(&cnt->vertices, (unsigned long long)__popcll(ml));
+    }
+    base = __shfl(base, leader);
+    if (has_shadow) queue[base + __popcll(ms & lanes_below())] = (uint32_t)slot;
+    if (has_ext) queue[base + ns + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
+  }
+}
+
+// ---- color / spp: src/Render.cpp:661-662 ----
+__global__ void __launch_bounds__(kBlock)
+k_resolve(RenderArgs a, const float4 *__restrict__ partial, float *__restrict__ rgb) {
+  int lp = blockIdx.x * kBlock + threadIdx.x;
+  if (lp >= a.n_pix) return;
+  V3 c = mk(0, 0, 0);
+  for (int ch = 0; ch < a.n_chunks; ch++) c = c + xyz(partial[(size_t)ch * a.n_pix + lp]);
+  c = c / (float)a.spp;
+  rgb[3 * (size_t)lp] = c.x;
+  rgb[3 * (size_t)lp + 1] = c.y;
+  rgb[3 * (size_t)lp + 2] = c.z;
+}
+
+// ---- unit-level entry points used by the parity tests ----
+struct ArrayStream {
+  const float *u;
+  uint32_t dim;
+  uint32_t n;
+  RTR_DEV float next() {
+    float v = dim < n ? u[dim] : 0.0f;
+    dim++;
+    return v;
+  }
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_material_eval(const DeviceMaterial *__restrict__ mats, const int32_t *__restrict__ mid,
+                const float *__restrict__ wi, const float *__restrict__ wo,
+                const float *__restrict__ nn, size_t n, float *__restrict__ f,
+                float *__restrict__ pdf) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  DeviceMaterial dm = mats[mid[i]];
+  V3 r = mat_eval(dm, mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]),
+                  mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]),
+                  mk(nn[3 * i], nn[3 * i + 1], nn[3 * i + 2]));
+  if (f) { f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z; }
+  if (pdf) pdf[i] = mat_pdf(dm);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_material_sample(const DeviceMaterial *__restrict__ mats, const int32_t *__restrict__ mid,
+                  const float *__restrict__ wi, const float *__restrict__ nn,
+                  const float *__restrict__ u2, size_t n, float *__restrict__ wo) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  DeviceMaterial dm = mats[mid[i]];
+  V3 w = mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+  V3 N = mk(nn[3 * i], nn[3 * i + 1], nn[3 * i + 2]);
+  V3 r = mat_kind(dm) == 1 ? mat_mirror(w, N) : mat_sample_uv(N, u2[2 * i], u2[2 * i + 1]);
+  wo[3 * i] = r.x; wo[3 * i + 1] = r.y; wo[3 * i + 2] = r.z;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_sample_light(DeviceScene sc, DeviceLights L, const float *__restrict__ u, int stride, size_t n,
+               float *__restrict__ pos, float *__restrict__ nrm, float *__restrict__ pdf,
+               int32_t *__restrict__ prim, int32_t *__restrict__ used) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  ArrayStream rng{u + (size_t)stride * i, 0u, (uint32_t)stride};
+  LightSample ls;
+  sample_light(sc, L, rng, ls);
+  pos[3 * i] = ls.pos.x; pos[3 * i + 1] = ls.pos.y; pos[3 * i + 2] = ls.pos.z;
+  nrm[3 * i] = ls.nrm.x; nrm[3 * i + 1] = ls.nrm.y; nrm[3 * i + 2] = ls.nrm.z;
+  pdf[i] = ls.pdf;
+  prim[i] = ls.leaf < 0 ? -1
+                        : ((ls.leaf >> 30) ? sc.sph_prim[ls.leaf & 0x3fffffff] : sc.tri_prim[ls.leaf]);
+  used[i] = (int32_t)rng.dim;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_stream_uniform(uint32_t seed, const uint32_t *__restrict__ pixel,
+                 const uint32_t *__restrict__ sample, const uint32_t *__restrict__ bounce,
+                 const uint32_t *__restrict__ dim, size_t n, float *__restrict__ u) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  VertexStream rng(seed, pixel[i], sample[i], bounce[i]);
+  rng.dim = dim[i];
+  u[i] = rng.next();
+}
+
+} // namespace rtr

@@ -1,0 +1,119 @@
+// Device-side fp32 vector math for the path-tracing kernels (gfx950).
+//
+// Every expression keeps the reference's operation order (include/Vector.h) and
+// is compiled with -ffp-contract=off: closest-hit results must equal the
+// reference's bit for bit, so a*b+c must stay two roundings, divisions must be
+// IEEE divisions (never reciprocal multiplies) and sqrt must be correctly
+// rounded (hipcc's default for fp32 when fast-math is off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RTR_DEV __device__ __forceinline__
+
+namespace rtr {
+
+struct V3 {
+  float x, y, z;
+};
+
+RTR_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+RTR_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RTR_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTR_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RTR_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RTR_DEV V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+RTR_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RTR_DEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// include/Vector.h:139-141 -- products summed left to right
+RTR_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// include/Vector.h:147-149
+RTR_DEV V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - b.z * a.x, a.x * b.y - a.y * b.x);
+}
+// include/Vector.h:79
+RTR_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// include/Vector.h:84-87 -- three divisions by the length
+RTR_DEV V3 unit(V3 a) {
+  float l = length(a);
+  return mk(a.x / l, a.y / l, a.z / l);
+}
+// std::max / std::min comparison directions (NaN behaviour differs from fmaxf)
+RTR_DEV float maxf(float a, float b) { return (a < b) ? b : a; }
+RTR_DEV float minf(float a, float b) { return (b < a) ? b : a; }
+// include/Global.h:15-18
+RTR_DEV float clampf(float lo, float hi, float v) { return maxf(lo, minf(hi, v)); }
+
+RTR_DEV V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+RTR_DEV float4 pack(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+RTR_DEV float4 pack(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+RTR_DEV uint32_t wbits(float4 v) { return __float_as_uint(v.w); }
+
+// sin and cos of x in [0, 2*pi] as a fixed sequence of fp32 multiplies and adds:
+// Cody-Waite reduction by pi/2 (three-term split, products with k <= 4 exact)
+// and the classic single-precision minimax polynomials on [-pi/4, pi/4].  The
+// same sequence evaluated on any IEEE-754 machine gives the same bits, which is
+// what lets a CPU checker reproduce the kernels' sample values exactly; device
+// libm and host libm differ in the last ulp.
+RTR_DEV void sincos_fixed(float x, float &s_out, float &c_out) {
+  float kf = floorf(x * 0.636619772f + 0.5f);
+  int k = (int)kf;
+  float r = x - kf * 1.5703125f;
+  r = r - kf * 4.837512969970703125e-4f;
+  r = r - kf * 7.54978995489188e-8f;
+  float z = r * r;
+  float sp = -1.9515295891e-4f;
+  sp = sp * z + 8.3321608736e-3f;
+  sp = sp * z + -1.6666654611e-1f;
+  float s = r + r * z * sp;
+  float cp = 2.443315711809948e-5f;
+  cp = cp * z + -1.388731625493765e-3f;
+  cp = cp * z + 4.166664568298827e-2f;
+  float c = 1.0f - 0.5f * z + z * z * cp;
+  int q = k & 3;
+  float ss = (q & 1) ? c : s;
+  float cc = (q & 1) ? s : c;
+  s_out = (q & 2) ? -ss : ss;
+  c_out = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
+RTR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// top 24 bits -> [0,1)
+RTR_DEV float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }
+
+// Uniform number `dim` of path vertex `bounce` of sample `sample` of pixel
+// `pixel`: word dim&3 of block (pixel, sample, bounce, dim>>2), key (seed, 0).
+struct VertexStream {
+  uint32_t seed, pixel, sample, bounce, dim;
+  uint32_t w[4];
+  int block;
+  RTR_DEV VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo)
+      : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), block(-1) {}
+  RTR_DEV float next() {
+    int b = (int)(dim >> 2);
+    if (b != block) {
+      philox4x32_10(pixel, sample, bounce, (uint32_t)b, seed, 0u, w);
+      block = b;
+    }
+    uint32_t d = dim & 3u;
+    uint32_t v = d == 0 ? w[0] : d == 1 ? w[1] : d == 2 ? w[2] : w[3];
+    dim++;
+    return u01(v);
+  }
+};
+
+} // namespace rtr

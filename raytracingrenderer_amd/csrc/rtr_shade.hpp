@@ -1,0 +1,204 @@
+// Materials and light sampling on the device: Material::eval / sample / pdf
+// (src/Material.cpp), Sphere::sample, Trangle::sample, TrangleMesh::sample,
+// Scene::samplingLight.  Expressions keep the reference's float/double
+// promotions: where the reference multiplies by the double literal MY_PI
+// (include/Global.h:4) the product is formed in fp64 and narrowed, exactly once.
+#pragma once
+#include "rtr_trace.hpp"
+
+namespace rtr {
+
+constexpr double kPi = 3.1415926;  // include/Global.h:4
+
+struct DeviceMaterial {  // 3 x float4
+  float4 e_kind;   // emission.xyz, bits(kind | emissive << 8)
+  float4 kd_ior;   // kd.xyz, ior
+  float4 ks_rough; // ks.xyz, roughness
+};
+
+struct DeviceLights {
+  const float4 *light;        // per light: { area, bits(kind), bits(prim or tri_begin), bits(tri_end) }
+  const int32_t *light_tris;  // triangle ROWS (not prim ids) in mesh leaf order
+  const float *tri_area;      // per triangle row
+  int32_t n_lights;
+  float total_area;           // sum in Scene::lights order, fp32 (src/Scene.cpp:17-20)
+};
+
+RTR_DEV int mat_kind(const DeviceMaterial &m) { return (int)(wbits(m.e_kind) & 0xff); }
+RTR_DEV bool mat_emissive(const DeviceMaterial &m) { return (wbits(m.e_kind) >> 8) & 1; }
+
+// src/Material.cpp:44-64
+RTR_DEV float fresnel_kr(V3 I, V3 N, float ior) {
+  float cosi = clampf(-1.0f, 1.0f, dot(I, N));
+  float etai = 1, etat = ior;
+  if (cosi > 0) { float tmp = etai; etai = etat; etat = tmp; }
+  float sint = etai / etat * sqrtf(maxf(0.f, 1 - cosi * cosi));
+  if (sint >= 1) return 1;
+  float cost = sqrtf(maxf(0.f, 1 - sint * sint));
+  cosi = fabsf(cosi);
+  float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+  float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+  return (Rs * Rs + Rp * Rp) / 2;
+}
+
+// src/Material.cpp:3-14
+RTR_DEV float ggx_d(float roughness, V3 N, V3 H) {
+  float a = roughness * roughness;
+  float a2 = a * a;
+  float nh = maxf(dot(unit(N), unit(H)), 0.0f);
+  float nh2 = nh * nh;
+  float den = (float)((double)nh2 * ((double)a2 - 1.0) + 1.0);
+  den = (float)(kPi * (double)den * (double)den);
+  return a2 / maxf(den, 0.0001f);
+}
+
+// src/Material.cpp:24-42
+RTR_DEV float smith_g(float roughness, V3 N, V3 V, V3 L) {
+  float r = (float)((double)roughness + 1.0);
+  float k = (float)((double)(r * r) / 8.0);
+  float nv = maxf(dot(N, V), 0.0f);
+  float nl = maxf(dot(N, L), 0.0f);
+  float g2 = nv / (float)((double)nv * (1.0 - (double)k) + (double)k);
+  float g1 = nl / (float)((double)nl * (1.0 - (double)k) + (double)k);
+  return g1 * g2;
+}
+
+// Material::eval, src/Material.cpp:66-95
+RTR_DEV V3 mat_eval(const DeviceMaterial &m, V3 wi, V3 wo, V3 n) {
+  V3 res = mk(0, 0, 0);
+  int kind = mat_kind(m);
+  V3 kd = xyz(m.kd_ior);
+  if (kind == 0) {
+    float c = dot(unit(wo), unit(n));
+    float f = c > 0.0f ? (float)(1.0f / kPi) : 0.0f;
+    res = kd * f;
+  } else if (kind == 1) {
+    V3 h = unit(wi) + unit(wo);
+    h = unit(h);
+    V3 N = unit(n);
+    res = ((double)dot(h, N) > (double)1.0f - 1e-3) ? kd : mk(0, 0, 0);
+  } else {
+    V3 ks = xyz(m.ks_rough);
+    float rough = m.ks_rough.w;
+    float kr = fresnel_kr(unit(wi), unit(n), m.kd_ior.w);
+    float d = ggx_d(rough, unit(n), unit(unit(wi) + unit(wo)));
+    float g = smith_g(rough, unit(n), unit(wi), unit(wo));
+    float co = dot(unit(wo), unit(n));
+    float ci = dot(unit(wi), unit(n));
+    res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + kd * (1 - kr) / (float)kPi;
+  }
+  return res;
+}
+
+// Material::pdf, src/Material.cpp:149-168
+RTR_DEV float mat_pdf(const DeviceMaterial &m) {
+  return mat_kind(m) == 1 ? 1.0f : (float)(0.5f / kPi);
+}
+
+// Material::sample, src/Material.cpp:97-147 (mirror: include/Material.h:80-84).
+// u1 drives alph, u2 drives theta -- the reference's draw order.
+RTR_DEV V3 mat_sample_uv(V3 n, float u1, float u2) {
+  float alph = (float)((double)(u1 * 2.0f) * kPi);
+  float theta = (float)((double)(u2 * 2.0f) * kPi);
+  float sa, ca, st, ct;
+  sincos_fixed(alph, sa, ca);
+  sincos_fixed(theta, st, ct);
+  V3 wo = mk(ca * ct, st, sa * ct);
+  if (dot(wo, n) < 0) wo = -wo;
+  return wo;
+}
+RTR_DEV V3 mat_mirror(V3 wi, V3 n) {
+  V3 i = unit(-wi);
+  V3 nn = unit(n);
+  return i - 2.0f * dot(nn, i) * nn;
+}
+
+struct LightSample {
+  V3 pos, nrm;
+  float pdf;
+  int32_t leaf;  // (kind << 30) | row of the sampled primitive, -1 if none
+};
+
+// Sphere::sample, src/Sphere.cpp:41-48 (theta is drawn before phi)
+template <class Rng>
+RTR_DEV void sample_sphere(const DeviceScene &sc, int row, float area, Rng &rng, LightSample &ls) {
+  float theta = (float)(2.0 * kPi * (double)rng.next());
+  float phi = (float)(kPi * (double)rng.next());
+  float st, ct, sp, cp;
+  sincos_fixed(theta, st, ct);
+  sincos_fixed(phi, sp, cp);
+  V3 d = mk(cp, sp * ct, sp * st);
+  float4 q = sc.sphs[row];
+  ls.pos = xyz(q) + q.w * d;
+  ls.nrm = d;
+  ls.leaf = (1 << 30) | row;
+  ls.pdf = 1.0f / area;
+}
+
+// Trangle::sample, src/Trangle.cpp:42-49
+template <class Rng>
+RTR_DEV void sample_triangle(const DeviceScene &sc, int row, float area, Rng &rng,
+                             LightSample &ls) {
+  float b1 = rng.next();
+  float b2 = (float)((double)rng.next() * (1.0 - (double)b1));
+  float4 q0 = sc.tris[3 * row], q1 = sc.tris[3 * row + 1], q2 = sc.tris[3 * row + 2];
+  ls.pos = (1 - b1 - b2) * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2);
+  ls.nrm = mk(q0.w, q1.w, q2.w);
+  ls.leaf = row;
+  ls.pdf = 1.0f / area;
+}
+
+// Object::sample for light l: Sphere::sample, or TrangleMesh::sample
+// (include/Trangle.h:103-108) whose walk (src/BVH.cpp:82-95) re-samples at every
+// leaf from the first selected one on, so the LAST leaf decides; the draws the
+// earlier leaves would have consumed are skipped by advancing the counter.
+template <class Rng>
+RTR_DEV void sample_object(const DeviceScene &sc, const DeviceLights &L, int l, Rng &rng,
+                           LightSample &ls) {
+  float4 rec = L.light[l];
+  float area = rec.x;
+  if (__float_as_int(rec.y) == 1) {
+    int prim = __float_as_int(rec.z);
+    sample_sphere(sc, sc.prim_kind_row[prim] & 0x3fffffff, area, rng, ls);
+    return;
+  }
+  ls.pdf = -1.0f;
+  float rest = rng.next() * area;
+  int b = __float_as_int(rec.z), e = __float_as_int(rec.w);
+  int first = -1;
+  for (int k = b; k < e; k++) {
+    rest -= L.tri_area[L.light_tris[k]];
+    if ((double)rest < 1e-3) { first = k; break; }
+  }
+  if (first >= 0) {
+    rng.dim += 2u * (uint32_t)(e - 1 - first);  // draws of the leaves that get overwritten
+    int row = L.light_tris[e - 1];
+    float a = L.tri_area[row];
+    sample_triangle(sc, row, a, rng, ls);
+    ls.pdf *= a;
+  }
+  ls.pdf /= area;
+}
+
+// Scene::samplingLight, src/Scene.cpp:16-35 (caller presets pdf = -1,
+// src/Render.cpp:91).
+template <class Rng>
+RTR_DEV void sample_light(const DeviceScene &sc, const DeviceLights &L, Rng &rng,
+                          LightSample &ls) {
+  ls.pdf = -1.0f;
+  ls.leaf = -1;
+  ls.pos = mk(0, 0, 0);
+  ls.nrm = mk(0, 0, 0);
+  float pick = rng.next() * L.total_area;
+  for (int i = 0; i < L.n_lights; i++) {
+    if ((double)pick < 1e-3) {
+      sample_object(sc, L, i, rng, ls);
+      break;
+    } else {
+      pick -= L.light[i].x;
+    }
+  }
+  if (ls.pdf < 0 && L.n_lights > 0) sample_object(sc, L, L.n_lights - 1, rng, ls);
+}
+
+} // namespace rtr

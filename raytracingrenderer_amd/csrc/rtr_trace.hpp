@@ -1,0 +1,219 @@
+// Closest-hit traversal and primitive tests for gfx950.
+//
+// Layout in HBM (built by rtr_scene_create):
+//   nodes : 2 x float4 per node, nodes numbered in depth-first pre-order (left
+//           child first), so the left child of inner node i is i+1:
+//             [2i]   = { bmin.x, bmin.y, bmin.z, bits(skip) }
+//             [2i+1] = { bmax.x, bmax.y, bmax.z, bits(leaf)  }
+//           skip = index of the first node after i's subtree (n_nodes at the
+//           end) -- where traversal continues when i's box is missed;
+//           leaf = -1 for an inner node, else (kind << 30) | row.
+//   tris  : 3 x float4 per triangle: {p0, n.x} {p1, n.y} {p2, n.z}
+//   sphs  : 1 x float4 per sphere:   {c, r}
+// A lane gathers whole nodes, so a node is one 32-byte record (two 16-byte
+// loads from one cache line) rather than eight separate arrays.
+//
+// Traversal is stackless: visiting nodes in pre-order and jumping over missed
+// subtrees through `skip` reaches exactly the leaves the reference's recursion
+// (src/BVH.cpp:66-80) reaches, in the same left-to-right order, with no
+// per-lane stack at all.  The reference merges the two subtrees' results with
+// "strictly nearer keeps the left one" (src/BVH.cpp:75-76); folding the leaves
+// left to right with the same rule gives the same winner whenever all hit
+// distances are ordered.  A hit distance can be NaN (degenerate triangle,
+// src/Trangle.cpp:13-17 with s_e == 0); then the tree-shaped merge and the fold
+// can differ, so such rays are re-traced by trace_tree(), which evaluates the
+// merge tree literally.
+#pragma once
+#include "rtr_math.hpp"
+
+namespace rtr {
+
+struct DeviceScene {
+  const float4 *nodes;
+  const float4 *tris;
+  const float4 *sphs;
+  const int32_t *tri_prim;  // triangle row -> prim id
+  const int32_t *sph_prim;  // sphere row   -> prim id
+  const int32_t *prim_kind_row;  // prim id -> (kind << 30) | row
+  const int32_t *prim_material;
+  int32_t n_nodes;
+  int32_t n_prims;
+};
+
+struct HitRec {
+  float t, b1, b2;
+  int32_t leaf;  // (kind << 30) | row, or -1 for a miss
+};
+
+constexpr int kMaxDepth = 64;
+
+// Bound3::intersect, src/Bound3.cpp:3-22, with the direction already
+// normalised by the caller (the reference normalises the same vector on every
+// call, src/Bound3.cpp:5; the result is the same each time).
+RTR_DEV bool slab(float4 lo, float4 hi, V3 o, V3 d) {
+  float ax = (lo.x - o.x) / d.x, bx = (hi.x - o.x) / d.x;
+  float nx = ax > bx ? bx : ax, fx = ax > bx ? ax : bx;
+  float ay = (lo.y - o.y) / d.y, by = (hi.y - o.y) / d.y;
+  float ny = ay > by ? by : ay, fy = ay > by ? ay : by;
+  float az = (lo.z - o.z) / d.z, bz = (hi.z - o.z) / d.z;
+  float nz = az > bz ? bz : az, fz = az > bz ? az : bz;
+  float tnear = nx > ny ? (nx > nz ? nx : nz) : (ny > nz ? ny : nz);
+  float tfar = fx < fy ? (fx < fz ? fx : fz) : (fy < fz ? fy : fz);
+  return tnear <= tfar;
+}
+
+// Trangle::intersect, src/Trangle.cpp:3-28.  `dir` is the ray direction as
+// given (used un-normalised by the back-face test, :5), `dn` its normalisation.
+RTR_DEV bool hit_triangle(const DeviceScene &sc, int row, V3 o, V3 dir, V3 dn, float &t,
+                          float &b1, float &b2) {
+  float4 q0 = sc.tris[3 * row], q1 = sc.tris[3 * row + 1], q2 = sc.tris[3 * row + 2];
+  V3 p0 = xyz(q0), p1 = xyz(q1), p2 = xyz(q2), n = mk(q0.w, q1.w, q2.w);
+  if (dot(-dir, n) < 0) return false;
+  V3 e1 = p1 - p0, e2 = p2 - p0, s = o - p0;
+  V3 s1 = cross(dn, e2), s2 = cross(s, e1);
+  float se = dot(s1, e1);
+  float inv = 1 / se;
+  t = inv * dot(s2, e2);
+  b1 = inv * dot(s1, s);
+  b2 = inv * dot(s2, dn);
+  // float operands against double literals, src/Trangle.cpp:17
+  if ((double)t < -1e-5 || (double)b1 < -1e-5 || (double)b2 < -1e-5 ||
+      (double)(1 - b1 - b2) < -1e-5)
+    return false;
+  return true;
+}
+
+// Sphere::intersect, src/Sphere.cpp:3-39.
+RTR_DEV bool hit_sphere(const DeviceScene &sc, int row, V3 org, V3 d, float &t) {
+  float4 q = sc.sphs[row];
+  V3 c = xyz(q);
+  float r = q.w;
+  V3 o = org - c;
+  if (length(o) < r) return false;
+  float a = d.x * d.x + d.y * d.y + d.z * d.z;
+  float b = 2 * (o.x * d.x + o.y * d.y + o.z * d.z);
+  float cc = o.x * o.x + o.y * o.y + o.z * o.z - r * r;
+  float delta = b * b - 4 * a * cc;
+  if (delta < 0) return false;
+  float sq = sqrtf(delta);
+  float t1 = (-b + sq) / 2 / a;
+  float t2 = (-b - sq) / 2 / a;
+  if ((double)t1 < 1e-3) return false;
+  t = (t2 < 0) ? t1 : t2;
+  return true;
+}
+
+RTR_DEV bool hit_leaf(const DeviceScene &sc, int leaf, V3 o, V3 dir, V3 dn, HitRec &h) {
+  int row = leaf & 0x3fffffff;
+  h.leaf = leaf;
+  if (leaf >> 30) {
+    h.b1 = 0;
+    h.b2 = 0;
+    return hit_sphere(sc, row, o, dn, h.t);
+  }
+  return hit_triangle(sc, row, o, dir, dn, h.t, h.b1, h.b2);
+}
+
+// Literal evaluation of the reference's merge tree (src/BVH.cpp:66-80) with an
+// explicit stack; only used for rays on which a NaN hit distance was seen.
+__device__ __noinline__ HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn) {
+  // frame: node index, phase (0 = enter, 1 = left done, 2 = right done), left result
+  int node[kMaxDepth];
+  unsigned char phase[kMaxDepth];
+  HitRec left[kMaxDepth];
+  int sp = 0;
+  node[0] = 0;
+  phase[0] = 0;
+  HitRec ret;
+  ret.leaf = -1;
+  ret.t = 0; ret.b1 = 0; ret.b2 = 0;
+  while (sp >= 0) {
+    int i = node[sp];
+    if (phase[sp] == 0) {
+      float4 lo = sc.nodes[2 * i], hi = sc.nodes[2 * i + 1];
+      int leaf = (int)wbits(hi);
+      ret.leaf = -1;
+      if (!slab(lo, hi, o, dn)) { sp--; continue; }
+      if (leaf >= 0) {
+        HitRec h;
+        if (hit_leaf(sc, leaf, o, dir, dn, h)) ret = h;
+        sp--;
+        continue;
+      }
+      phase[sp] = 1;
+      if (sp + 1 >= kMaxDepth) { ret.leaf = -1; return ret; }  // rejected at scene creation
+      node[sp + 1] = i + 1;
+      phase[sp + 1] = 0;
+      sp++;
+    } else if (phase[sp] == 1) {
+      left[sp] = ret;
+      phase[sp] = 2;
+      node[sp + 1] = (int)wbits(sc.nodes[2 * (i + 1)]);  // right child = skip of the left child
+      phase[sp + 1] = 0;
+      sp++;
+    } else {
+      HitRec l = left[sp], r = ret, out;
+      out.leaf = -1; out.t = 0; out.b1 = 0; out.b2 = 0;
+      out = (l.leaf >= 0) ? l : out;
+      out = (r.leaf >= 0) ? ((out.leaf >= 0) ? ((out.t < r.t) ? out : r) : r) : out;
+      ret = out;
+      sp--;
+    }
+  }
+  return ret;
+}
+
+// Scene::intersect for one ray.
+RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn) {
+  HitRec best;
+  best.leaf = -1;
+  best.t = 0; best.b1 = 0; best.b2 = 0;
+  bool saw_nan = false;
+  int i = 0;
+  const int n = sc.n_nodes;
+  while (i < n) {
+    float4 lo = sc.nodes[2 * i], hi = sc.nodes[2 * i + 1];
+    int skip = (int)wbits(lo);
+    int leaf = (int)wbits(hi);
+    if (slab(lo, hi, o, dn)) {
+      if (leaf >= 0) {
+        HitRec h;
+        if (hit_leaf(sc, leaf, o, dir, dn, h)) {
+          saw_nan |= (h.t != h.t);
+          bool keep = (best.leaf >= 0) && (best.t < h.t);
+          if (!keep) best = h;
+        }
+        i = skip;  // a leaf's subtree is itself
+      } else {
+        i = i + 1;
+      }
+    } else {
+      i = skip;
+    }
+  }
+  if (saw_nan) best = trace_tree(sc, o, dir, dn);
+  return best;
+}
+
+// Intersection::postion / ::normal of a recorded hit (src/Trangle.cpp:23-24,
+// src/Sphere.cpp:25-26 / :33-34).
+RTR_DEV void hit_point(const DeviceScene &sc, const HitRec &h, V3 o, V3 dn, V3 &pos, V3 &nrm) {
+  int row = h.leaf & 0x3fffffff;
+  if (h.leaf >> 30) {
+    float4 q = sc.sphs[row];
+    pos = o + dn * h.t;
+    nrm = unit(pos - xyz(q));
+  } else {
+    float4 q0 = sc.tris[3 * row], q1 = sc.tris[3 * row + 1], q2 = sc.tris[3 * row + 2];
+    pos = xyz(q0) * (1 - h.b1 - h.b2) + xyz(q1) * h.b1 + xyz(q2) * h.b2;
+    nrm = mk(q0.w, q1.w, q2.w);
+  }
+}
+
+RTR_DEV int hit_prim(const DeviceScene &sc, const HitRec &h) {
+  if (h.leaf < 0) return -1;
+  int row = h.leaf & 0x3fffffff;
+  return (h.leaf >> 30) ? sc.sph_prim[row] : sc.tri_prim[row];
+}
+
+} // namespace rtr

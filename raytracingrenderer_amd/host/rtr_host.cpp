@@ -1,0 +1,672 @@
+// Host-side mirror of the reference's scene API: construction, the BVH build,
+// flattening into the C ABI's arrays, and Render on top of the device library.
+// See rtr_host.hpp.  No ray is intersected and no sample is shaded on the CPU.
+#include "rtr_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <stdexcept>
+
+// ---------------- vectors ----------------
+float Vector3f::getLen() const { return sqrtf(x * x + y * y + z * z); }
+Vector3f Vector3f::normalize() const {
+  float len = getLen();
+  return Vector3f(x / len, y / len, z / len);
+}
+float vec::dotProduct(const Vector3f &a, const Vector3f &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+Vector3f vec::crossProduct(const Vector3f &a, const Vector3f &b) {
+  return Vector3f(a.y * b.z - a.z * b.y, a.z * b.x - b.z * a.x, a.x * b.y - a.y * b.x);
+}
+
+// ---------------- Bound3 (include/Bound3.h:10-22) ----------------
+Bound3::Bound3()
+    : min(std::numeric_limits<float>::max()), max(std::numeric_limits<float>::lowest()) {}
+
+Bound3 &Bound3::merge(const Bound3 &b) {
+  Vector3f lo(min.x < b.min.x ? min.x : b.min.x, min.y < b.min.y ? min.y : b.min.y,
+              min.z < b.min.z ? min.z : b.min.z);
+  Vector3f hi(max.x > b.max.x ? max.x : b.max.x, max.y > b.max.y ? max.y : b.max.y,
+              max.z > b.max.z ? max.z : b.max.z);
+  min = lo;
+  max = hi;
+  return *this;
+}
+
+Vector3f Bound3::getCenterPos() const { return min * 0.5f + max * 0.5f; }
+
+// ---------------- Material (include/Material.h:53-65) ----------------
+Material::Material(MaterialType _type, Vector3f _emission, Vector3f _kd, Vector3f _ks, float _ior,
+                   float _roughness, float _specularExponent)
+    : type(_type), emission(_emission), kd(_kd), ks(_ks) {
+  ior = (float)(_ior > 0 ? (double)_ior : 1e-5);
+  roughness = (float)(_roughness > 0 ? (double)(_roughness < 1.0f ? _roughness : 1.0f) : 1e-5);
+  specularExponent = _specularExponent > 1 ? _specularExponent : 1.0f;
+}
+
+bool Material::hasEmission() const {
+  return (double)emission.x > 1e-4 || (double)emission.y > 1e-4 || (double)emission.z > 1e-4;
+}
+
+// ---------------- Sphere (include/Sphere.h:11-21) ----------------
+Sphere::Sphere(Material *_material, Vector3f _center, float _radius) : Object(_material) {
+  center = _center;
+  radius = _radius > 0 ? _radius : 0;
+  bound = Bound3(center - Vector3f(radius), center + Vector3f(radius));
+  area = (float)(4.0 * MY_PI * radius * radius);
+}
+
+// ---------------- Trangle (include/Trangle.h:17-38, src/Trangle.cpp:30-40) ----------------
+static float min3(float a, float b, float c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); }
+static float max3(float a, float b, float c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+Trangle::Trangle(Material *_material, Vector3f _p0, Vector3f _p1, Vector3f _p2, Vector3f _normal,
+                 Vector2f _uv0, Vector2f _uv1, Vector2f _uv2)
+    : Object(_material), p0(_p0), p1(_p1), p2(_p2), uv0(_uv0), uv1(_uv1), uv2(_uv2) {
+  Vector3f faceCross = vec::crossProduct(p1 - p0, p2 - p0);
+  // a supplied normal is used only when it is (close to) unit length; a NaN one
+  // fails the comparison and the geometric normal is taken
+  if ((double)(_normal.x * _normal.x + _normal.y * _normal.y + _normal.z * _normal.z) >= 1.0 - 1e-4)
+    normal = _normal.normalize();
+  else
+    normal = faceCross.normalize();
+  bound = Bound3(Vector3f(min3(p0.x, p1.x, p2.x), min3(p0.y, p1.y, p2.y), min3(p0.z, p1.z, p2.z)),
+                 Vector3f(max3(p0.x, p1.x, p2.x), max3(p0.y, p1.y, p2.y), max3(p0.z, p1.z, p2.z)));
+  area = faceCross.getLen();  // twice the geometric area, as in the reference
+}
+
+// ---------------- BVH (src/BVH.cpp:19-64) ----------------
+void BVH::destroy(BVHNode *n) {
+  if (!n) return;
+  destroy(n->left);
+  destroy(n->right);
+  delete n;
+}
+
+BVHNode *BVH::build(std::vector<Object *> &objs) {
+  if (objs.empty()) return nullptr;
+  BVHNode *node = new BVHNode();
+  Bound3 all;
+  for (Object *o : objs) all.merge(o->getBound());
+  node->bound = all;
+  if (objs.size() == 1) {
+    node->object = objs[0];
+    return node;
+  }
+  const float ex = all.max.x - all.min.x, ey = all.max.y - all.min.y, ez = all.max.z - all.min.z;
+  const int axis = ex > ey ? (ex > ez ? 0 : 2) : (ey > ez ? 1 : 2);
+  auto key = [axis](Object *o) {
+    Vector3f c = o->getBound().getCenterPos();
+    return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+  };
+  std::sort(objs.begin(), objs.end(), [&](Object *a, Object *b) { return key(a) < key(b); });
+  const size_t half = objs.size() / 2;
+  std::vector<Object *> lower(objs.begin(), objs.begin() + half);
+  std::vector<Object *> upper(objs.begin() + half, objs.end());
+  node->left = build(lower);
+  node->right = build(upper);
+  return node;
+}
+
+void BVH::buildBVH(std::vector<Object *> &objs) {
+  destroy(root);
+  root = build(objs);
+}
+
+// ---------------- TrangleMesh (include/Trangle.h:60-95) ----------------
+TrangleMesh::TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
+                         std::vector<unsigned int> *_posIndices, std::vector<Vector3f> *_normals,
+                         std::vector<Vector2f> *_textureCoords)
+    : Object(_material), bvh(nullptr) {
+  if (!_positions || !_posIndices) throw std::invalid_argument("TrangleMesh: null positions/indices");
+  if (_posIndices->size() % 3 != 0) throw std::invalid_argument("TrangleMesh: indices are not triples");
+  const std::vector<Vector3f> &P = *_positions;
+  const std::vector<unsigned int> &I = *_posIndices;
+  trangles.resize(I.size() / 3);
+  area = 0;
+  for (size_t k = 0; k < I.size(); k += 3) {
+    const unsigned a = I[k], b = I[k + 1], c = I[k + 2];
+    if (a >= P.size() || b >= P.size() || c >= P.size())
+      throw std::out_of_range("TrangleMesh: vertex index out of range");
+    Vector3f n(0);
+    Vector2f uv[3];
+    if (_normals) n = (*_normals)[a] + (*_normals)[b] + (*_normals)[c];
+    if (_textureCoords) {
+      uv[0] = (*_textureCoords)[a];
+      uv[1] = (*_textureCoords)[b];
+      uv[2] = (*_textureCoords)[c];
+    }
+    // without normals this passes normalize(0) = NaN, which selects the face normal
+    Trangle *t = new Trangle(_material, P[a], P[b], P[c], n.normalize(), uv[0], uv[1], uv[2]);
+    t->indexInMesh = (int)(k / 3);
+    area += t->getArea();
+    trangles[k / 3] = t;
+  }
+  bvh = new BVH();
+  bvh->buildBVH(trangles);
+  if (!trangles.empty()) bound = bvh->getBound();
+}
+
+TrangleMesh::~TrangleMesh() {
+  delete bvh;
+  for (Object *t : trangles) delete t;
+}
+
+// ---------------- Scene (include/Scene.h:33-46) ----------------
+static void rtr_check(int rc, const char *what) {
+  if (rc != RTR_OK) throw std::runtime_error(std::string(what) + ": " + rtr_last_error());
+}
+
+Scene::Scene(Camera *_camera) : camera(_camera), bvh(new BVH()) {}
+
+Scene::~Scene() {
+  if (device) rtr_scene_destroy(device);
+  delete bvh;
+}
+
+void Scene::addObject(Object *obj) {
+  objects.push_back(obj);
+  addOrder.push_back(obj);
+  if (obj->getMaterial()->hasEmission()) lights.push_back(obj);
+  flatValid = false;
+}
+
+void Scene::rebuildBVH() {
+  bvh->buildBVH(objects);
+  flatValid = false;
+}
+
+void Scene::setDevice(int index) {
+  if (index != deviceIndex && device) {
+    rtr_scene_destroy(device);
+    device = nullptr;
+  }
+  deviceIndex = index;
+}
+
+namespace {
+
+struct Flattener {
+  FlatScene &f;
+  std::map<const Object *, int> prim_of;
+  std::map<const Material *, int> mat_of;
+
+  int material_id(const Material *m) {
+    auto it = mat_of.find(m);
+    if (it != mat_of.end()) return it->second;
+    int id = (int)f.mat_kind.size();
+    mat_of[m] = id;
+    f.mat_kind.push_back((int)m->getMaterialType());
+    Vector3f e = m->getEmission(), kd = m->getKd(), ks = m->getKs();
+    const float ev[3] = {e.x, e.y, e.z}, kdv[3] = {kd.x, kd.y, kd.z}, ksv[3] = {ks.x, ks.y, ks.z};
+    for (int a = 0; a < 3; a++) {
+      f.mat_emission[a].push_back(ev[a]);
+      f.mat_kd[a].push_back(kdv[a]);
+      f.mat_ks[a].push_back(ksv[a]);
+    }
+    f.mat_ior.push_back(m->getIor());
+    f.mat_roughness.push_back(m->getRoughness());
+    return id;
+  }
+
+  void add_sphere(const Sphere *s) {
+    int prim = (int)f.prim_kind.size();
+    prim_of[s] = prim;
+    f.prim_kind.push_back(RTR_PRIM_SPHERE);
+    f.prim_index.push_back((int)f.sph_r.size());
+    f.prim_material.push_back(material_id(s->getMaterial()));
+    f.prim_object.push_back(const_cast<Sphere *>(s));
+    Vector3f c = s->getCenter();
+    f.sph_c[0].push_back(c.x);
+    f.sph_c[1].push_back(c.y);
+    f.sph_c[2].push_back(c.z);
+    f.sph_r.push_back(s->getRadius());
+    f.sph_area.push_back(s->getArea());
+  }
+
+  void collect_triangles(const BVHNode *n, std::vector<const Trangle *> &out) {
+    if (!n) return;
+    if (n->object) {
+      out.push_back(static_cast<const Trangle *>(n->object));
+    } else {
+      collect_triangles(n->left, out);
+      collect_triangles(n->right, out);
+    }
+  }
+
+  void add_mesh(const TrangleMesh *m) {
+    std::vector<const Trangle *> leaf_order;
+    collect_triangles(m->getBVH()->getRoot(), leaf_order);
+    std::vector<const Trangle *> by_index(leaf_order.size(), nullptr);
+    for (const Trangle *t : leaf_order) by_index[t->indexInMesh] = t;
+    int mat = material_id(m->getMaterial());
+    for (const Trangle *t : by_index) {  // prim ids follow the index-triple order
+      int prim = (int)f.prim_kind.size();
+      prim_of[t] = prim;
+      f.prim_kind.push_back(RTR_PRIM_TRIANGLE);
+      f.prim_index.push_back((int)f.tri_area.size());
+      f.prim_material.push_back(mat);
+      f.prim_object.push_back(const_cast<Trangle *>(t));
+      const Vector3f *p[3] = {&t->P0(), &t->P1(), &t->P2()};
+      std::vector<float> *dst[3] = {f.tri_p0, f.tri_p1, f.tri_p2};
+      for (int v = 0; v < 3; v++) {
+        dst[v][0].push_back(p[v]->x);
+        dst[v][1].push_back(p[v]->y);
+        dst[v][2].push_back(p[v]->z);
+      }
+      f.tri_n[0].push_back(t->getNormal().x);
+      f.tri_n[1].push_back(t->getNormal().y);
+      f.tri_n[2].push_back(t->getNormal().z);
+      f.tri_area.push_back(t->getArea());
+    }
+  }
+
+  int add_node(const BVHNode *n) {
+    // a mesh leaf of the top-level tree is replaced by the mesh's own tree: its
+    // root carries the same bound (include/Trangle.h:56), so the second box test
+    // the reference performs there cannot change the outcome
+    if (n->object && n->object->kind() == Object::MESH) {
+      const BVHNode *inner = static_cast<const TrangleMesh *>(n->object)->getBVH()->getRoot();
+      if (inner) return add_node(inner);
+    }
+    int id = (int)f.node_prim.size();
+    const float lo[3] = {n->bound.min.x, n->bound.min.y, n->bound.min.z};
+    const float hi[3] = {n->bound.max.x, n->bound.max.y, n->bound.max.z};
+    for (int a = 0; a < 3; a++) {
+      f.node_bmin[a].push_back(lo[a]);
+      f.node_bmax[a].push_back(hi[a]);
+    }
+    f.node_left.push_back(-1);
+    f.node_right.push_back(-1);
+    f.node_prim.push_back(-1);
+    if (n->object) {
+      f.node_prim[id] = prim_of.at(n->object);
+    } else {
+      int l = add_node(n->left);
+      int r = add_node(n->right);
+      f.node_left[id] = l;
+      f.node_right[id] = r;
+    }
+    return id;
+  }
+};
+
+}  // namespace
+
+rtr_scene_desc FlatScene::desc() const {
+  rtr_scene_desc d;
+  memset(&d, 0, sizeof(d));
+  d.n_nodes = (int32_t)node_prim.size();
+  d.root = 0;
+  for (int a = 0; a < 3; a++) {
+    d.node_bmin[a] = node_bmin[a].data();
+    d.node_bmax[a] = node_bmax[a].data();
+    d.tri_p0[a] = tri_p0[a].data();
+    d.tri_p1[a] = tri_p1[a].data();
+    d.tri_p2[a] = tri_p2[a].data();
+    d.tri_n[a] = tri_n[a].data();
+    d.sph_c[a] = sph_c[a].data();
+    d.mat_emission[a] = mat_emission[a].data();
+    d.mat_kd[a] = mat_kd[a].data();
+    d.mat_ks[a] = mat_ks[a].data();
+  }
+  d.node_left = node_left.data();
+  d.node_right = node_right.data();
+  d.node_prim = node_prim.data();
+  d.n_prims = (int32_t)prim_kind.size();
+  d.prim_kind = prim_kind.data();
+  d.prim_index = prim_index.data();
+  d.prim_material = prim_material.data();
+  d.n_tris = (int32_t)tri_area.size();
+  d.tri_area = tri_area.data();
+  d.n_spheres = (int32_t)sph_r.size();
+  d.sph_r = sph_r.data();
+  d.sph_area = sph_area.data();
+  d.n_materials = (int32_t)mat_kind.size();
+  d.mat_kind = mat_kind.data();
+  d.mat_ior = mat_ior.data();
+  d.mat_roughness = mat_roughness.data();
+  d.n_lights = (int32_t)light_kind.size();
+  d.light_kind = light_kind.data();
+  d.light_prim = light_prim.data();
+  d.light_area = light_area.data();
+  d.light_tri_begin = light_tri_begin.data();
+  d.light_tris = light_tris.data();
+  return d;
+}
+
+const FlatScene &Scene::flatten() {
+  if (flatValid) return flat;
+  flat = FlatScene();
+  Flattener fl{flat, {}, {}};
+  for (Object *o : addOrder) {
+    if (o->kind() == Object::SPHERE) fl.add_sphere(static_cast<Sphere *>(o));
+    else if (o->kind() == Object::MESH) fl.add_mesh(static_cast<TrangleMesh *>(o));
+    else throw std::invalid_argument("Scene: only Sphere and TrangleMesh can be added");
+  }
+  if (bvh->getRoot()) fl.add_node(bvh->getRoot());
+  flat.light_tri_begin.push_back(0);
+  for (Object *l : lights) {
+    flat.light_area.push_back(l->getArea());
+    if (l->kind() == Object::SPHERE) {
+      flat.light_kind.push_back(RTR_PRIM_SPHERE);
+      flat.light_prim.push_back(fl.prim_of.at(l));
+    } else {
+      flat.light_kind.push_back(RTR_PRIM_TRIANGLE);
+      flat.light_prim.push_back(-1);
+      std::vector<const Trangle *> leaf_order;
+      fl.collect_triangles(static_cast<TrangleMesh *>(l)->getBVH()->getRoot(), leaf_order);
+      for (const Trangle *t : leaf_order) flat.light_tris.push_back(fl.prim_of.at(t));
+    }
+    flat.light_tri_begin.push_back((int32_t)flat.light_tris.size());
+  }
+  flatValid = true;
+  if (device) {
+    rtr_scene_destroy(device);
+    device = nullptr;
+  }
+  return flat;
+}
+
+rtr_scene *Scene::deviceScene() {
+  flatten();
+  if (!device) {
+    rtr_scene_desc d = flat.desc();
+    rtr_check(rtr_scene_create(&d, deviceIndex, &device), "rtr_scene_create");
+  }
+  return device;
+}
+
+void Scene::intersectBatch(const float *org_xyz, const float *dir_xyz, size_t n, int32_t *prim_id,
+                           float *t, float *pos_xyz, float *nrm_xyz) {
+  rtr_check(rtr_trace_closest(deviceScene(), org_xyz, dir_xyz, n, prim_id, t, pos_xyz, nrm_xyz),
+            "rtr_trace_closest");
+}
+
+Intersection Scene::intersect(const Ray &ray) {
+  const float o[3] = {ray.startPos.x, ray.startPos.y, ray.startPos.z};
+  const float d[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
+  int32_t prim = -1;
+  float t = 0, pos[3], nrm[3];
+  intersectBatch(o, d, 1, &prim, &t, pos, nrm);
+  Intersection it;
+  if (prim >= 0) {
+    it.hit = true;
+    it.distance = t;
+    it.postion = Vector3f(pos[0], pos[1], pos[2]);
+    it.normal = Vector3f(nrm[0], nrm[1], nrm[2]);
+    it.object = flat.prim_object[prim];
+  }
+  return it;
+}
+
+// ---------------- Render (src/Render.cpp:3-21, 632-694) ----------------
+static float clamp01(float v) { return std::max(0.0f, std::min(1.0f, v)); }
+
+void Render::saveFile(const std::vector<Vector3f> &pixels, const std::string &fileName,
+                      unsigned int height, unsigned int width) {
+  FILE *fp = fopen((fileName + ".ppm").c_str(), "wb");
+  if (!fp) throw std::runtime_error("Render::saveFile: cannot open " + fileName + ".ppm");
+  // the reference prints height before width, so viewers show the image transposed
+  fprintf(fp, "P6\n%d %d\n255\n", height, width);
+  std::vector<unsigned char> row(3 * (size_t)height * width);
+  for (size_t i = 0; i < (size_t)height * width; i++) {
+    row[3 * i] = (unsigned char)(255 * powf(clamp01(pixels[i].x), 0.6f));
+    row[3 * i + 1] = (unsigned char)(255 * powf(clamp01(pixels[i].y), 0.6f));
+    row[3 * i + 2] = (unsigned char)(255 * powf(clamp01(pixels[i].z), 0.6f));
+  }
+  fwrite(row.data(), 1, row.size(), fp);
+  fclose(fp);
+}
+
+void Render::renderPathTracing(Scene &scene, const unsigned int &imageWidth,
+                               const unsigned int &imageHeight, const unsigned int &spp,
+                               std::string fileName) {
+  std::cout << "render start, spp = " << spp << "\n";
+  auto start = std::chrono::steady_clock::now();
+  const Camera *c = scene.getCamera();
+  rtr_camera cam;
+  const Vector3f *src[3] = {&c->position, &c->frontDir, &c->upDir};
+  float *dst[3] = {cam.position, cam.front, cam.up};
+  for (int k = 0; k < 3; k++) {
+    dst[k][0] = src[k]->x;
+    dst[k][1] = src[k]->y;
+    dst[k][2] = src[k]->z;
+  }
+  cam.fov = c->fov;
+  rtr_render_params p;
+  memset(&p, 0, sizeof(p));
+  p.width = (int32_t)imageWidth;
+  p.height = (int32_t)imageHeight;
+  p.spp = (int32_t)spp;
+  p.seed = options.seed;
+  p.max_depth = options.max_depth;
+  p.rr_prob = options.rr_prob;
+  p.chunk_spp = options.chunk_spp;
+  p.pool_size = options.pool_size;
+  p.part_index = options.part_index;
+  p.part_count = options.part_count;
+  p.tile_cols = options.tile_cols;
+  p.profile = options.profile ? 1 : 0;
+  int32_t n_cols = 0;
+  rtr_check(rtr_partition_columns(p.width, p.part_index, p.part_count, p.tile_cols, &n_cols, nullptr),
+            "rtr_partition_columns");
+  delete buffer;
+  buffer = new std::vector<Vector3f>((size_t)n_cols * imageHeight);
+  static_assert(sizeof(Vector3f) == 3 * sizeof(float), "Vector3f must be three packed floats");
+  rtr_check(rtr_render_pt(scene.deviceScene(), &cam, &p, reinterpret_cast<float *>(buffer->data()),
+                          &lastStats),
+            "rtr_render_pt");
+  if (!fileName.empty()) saveFile(*buffer, fileName, imageHeight, (unsigned)n_cols);
+  std::cout << "render end, spp = " << spp << "\n";
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count();
+  std::cout << "Render complete: \nTime taken: " << ms << " ms\n";
+}
+
+void Render::render(Scene &scene, const unsigned int &imageWidth, const unsigned int &imageHeight,
+                    const unsigned int &spp, std::string fileName, RenderType type) {
+  if (type != RenderType::PathTracing) throw std::invalid_argument("Render::render: unknown RenderType");
+  renderPathTracing(scene, imageWidth, imageHeight, spp, fileName);
+}
+
+// ---------------- C facade for language bindings (tests drive it with ctypes) ----------------
+namespace {
+struct HostScene {
+  Camera *camera = nullptr;
+  Scene *scene = nullptr;
+  std::vector<Material *> mats;
+  std::vector<Object *> objs;
+  Render render;
+  std::string error;
+  ~HostScene() {
+    delete scene;
+    for (Object *o : objs) delete o;
+    for (Material *m : mats) delete m;
+    delete camera;
+  }
+};
+thread_local std::string g_host_error;
+template <class F>
+int guarded(F &&fn) {
+  try {
+    fn();
+    return 0;
+  } catch (const std::exception &e) {
+    g_host_error = e.what();
+    return -1;
+  }
+}
+Vector3f v3(const float *p) { return Vector3f(p[0], p[1], p[2]); }
+}  // namespace
+
+extern "C" {
+
+const char *rtrh_last_error(void) { return g_host_error.c_str(); }
+
+void *rtrh_scene_new(const float pos[3], const float front[3], const float up[3], float fov) {
+  HostScene *h = new HostScene();
+  h->camera = new Camera(v3(pos), v3(front), v3(up), fov);
+  h->scene = new Scene(h->camera);
+  return h;
+}
+
+void rtrh_scene_free(void *hs) { delete (HostScene *)hs; }
+
+int rtrh_add_material(void *hs, int kind, const float e[3], const float kd[3], const float ks[3],
+                      float ior, float roughness) {
+  HostScene *h = (HostScene *)hs;
+  h->mats.push_back(new Material((MaterialType)kind, v3(e), v3(kd), v3(ks), ior, roughness));
+  return (int)h->mats.size() - 1;
+}
+
+int rtrh_add_sphere(void *hs, int material, const float c[3], float radius) {
+  HostScene *h = (HostScene *)hs;
+  int id = -1;
+  guarded([&] {
+    Sphere *s = new Sphere(h->mats.at(material), v3(c), radius);
+    h->objs.push_back(s);
+    h->scene->addObject(s);
+    id = (int)h->objs.size() - 1;
+  });
+  return id;
+}
+
+int rtrh_add_mesh(void *hs, int material, const float *positions, int n_pos, const uint32_t *idx,
+                  int n_idx) {
+  HostScene *h = (HostScene *)hs;
+  int id = -1;
+  guarded([&] {
+    std::vector<Vector3f> pos(n_pos);
+    for (int i = 0; i < n_pos; i++) pos[i] = v3(positions + 3 * i);
+    std::vector<unsigned int> ind(idx, idx + n_idx);
+    TrangleMesh *m = new TrangleMesh(h->mats.at(material), &pos, &ind);
+    h->objs.push_back(m);
+    h->scene->addObject(m);
+    id = (int)h->objs.size() - 1;
+  });
+  return id;
+}
+
+int rtrh_build(void *hs) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] { h->scene->rebuildBVH(); });
+}
+
+// tree in the flattener's numbering (depth-first, left first); NULL arrays -> count only
+int rtrh_flatten(void *hs, float *bmin3, float *bmax3, int32_t *child2, int32_t *prim) {
+  HostScene *h = (HostScene *)hs;
+  int n = -1;
+  guarded([&] {
+    const FlatScene &f = h->scene->flatten();
+    n = (int)f.node_prim.size();
+    for (int i = 0; i < n; i++) {
+      for (int a = 0; a < 3; a++) {
+        if (bmin3) bmin3[3 * i + a] = f.node_bmin[a][i];
+        if (bmax3) bmax3[3 * i + a] = f.node_bmax[a][i];
+      }
+      if (child2) {
+        child2[2 * i] = f.node_left[i];
+        child2[2 * i + 1] = f.node_right[i];
+      }
+      if (prim) prim[i] = f.node_prim[i];
+    }
+  });
+  return n;
+}
+
+int rtrh_num_prims(void *hs) {
+  HostScene *h = (HostScene *)hs;
+  int n = -1;
+  guarded([&] { n = (int)h->scene->flatten().prim_kind.size(); });
+  return n;
+}
+
+float rtrh_object_area(void *hs, int object) {
+  HostScene *h = (HostScene *)hs;
+  return h->objs.at(object)->getArea();
+}
+
+// light table as handed to the device: kinds, areas, and mesh-light leaf orders
+int rtrh_lights(void *hs, int32_t *kind, int32_t *prim, float *area, int32_t *tri_begin,
+                int32_t *tris, int32_t *n_tris) {
+  HostScene *h = (HostScene *)hs;
+  int n = -1;
+  guarded([&] {
+    const FlatScene &f = h->scene->flatten();
+    n = (int)f.light_kind.size();
+    for (int i = 0; i < n; i++) {
+      if (kind) kind[i] = f.light_kind[i];
+      if (prim) prim[i] = f.light_prim[i];
+      if (area) area[i] = f.light_area[i];
+    }
+    if (tri_begin) memcpy(tri_begin, f.light_tri_begin.data(), 4 * f.light_tri_begin.size());
+    if (tris) memcpy(tris, f.light_tris.data(), 4 * f.light_tris.size());
+    if (n_tris) *n_tris = (int32_t)f.light_tris.size();
+  });
+  return n;
+}
+
+int rtrh_set_device(void *hs, int device) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] { h->scene->setDevice(device); });
+}
+
+// the rtr_scene* behind this scene (uploads on first use); NULL on failure
+rtr_scene *rtrh_device_scene(void *hs) {
+  HostScene *h = (HostScene *)hs;
+  rtr_scene *s = nullptr;
+  guarded([&] { s = h->scene->deviceScene(); });
+  return s;
+}
+
+int rtrh_material_id(void *hs, int material) {
+  // id of the host material in the flattened table (-1 if no primitive uses it)
+  HostScene *h = (HostScene *)hs;
+  int id = -1;
+  guarded([&] {
+    const FlatScene &f = h->scene->flatten();
+    const Material *m = h->mats.at(material);
+    for (size_t p = 0; p < f.prim_object.size(); p++)
+      if (f.prim_object[p]->getMaterial() == m) {
+        id = f.prim_material[p];
+        break;
+      }
+  });
+  return id;
+}
+
+int rtrh_intersect(void *hs, const float *org, const float *dir, int64_t n, int32_t *prim, float *t,
+                   float *pos, float *nrm) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] { h->scene->intersectBatch(org, dir, (size_t)n, prim, t, pos, nrm); });
+}
+
+// Render::renderPathTracing; file may be NULL/"" (no PPM).  rgb gets the buffer.
+int rtrh_render(void *hs, unsigned W, unsigned H, unsigned spp, const char *file,
+                const rtr_render_params *opt, float *rgb, rtr_stats *stats) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] {
+    if (opt) {
+      h->render.options.seed = opt->seed;
+      h->render.options.max_depth = opt->max_depth;
+      h->render.options.rr_prob = opt->rr_prob;
+      h->render.options.chunk_spp = opt->chunk_spp;
+      h->render.options.pool_size = opt->pool_size;
+      h->render.options.part_index = opt->part_index;
+      h->render.options.part_count = opt->part_count > 0 ? opt->part_count : 1;
+      h->render.options.tile_cols = opt->tile_cols;
+      h->render.options.profile = opt->profile != 0;
+    }
+    h->render.renderPathTracing(*h->scene, W, H, spp, file ? std::string(file) : std::string());
+    const std::vector<Vector3f> &b = h->render.getBuffer();
+    if (rgb) memcpy(rgb, b.data(), b.size() * sizeof(Vector3f));
+    if (stats) *stats = h->render.getStats();
+  });
+}
+
+} /* extern "C" */

@@ -1,0 +1,276 @@
+// Host-side mirror of the reference's scene API for the path-tracing path.
+//
+// A program written against the reference (src/main.cpp:7-90) builds Material,
+// Sphere, TrangleMesh, Camera and Scene objects, calls Scene::rebuildBVH and then
+// Render::renderPathTracing.  The classes below keep those names, constructor
+// signatures and argument meanings, so such a program compiles against this
+// header unchanged; what differs is where the work happens.  Nothing here
+// intersects or shades on the CPU: the Scene is flattened into the arrays of
+// include/rtr.h and every query or render goes through that C ABI to the HIP
+// kernels.  If the device library cannot run, calls throw std::runtime_error
+// with the library's message -- there is no CPU fallback.
+//
+// The tree built here must have the reference's exact topology and bounds, so
+// the build (longest axis, std::sort on box centres, split at size/2) follows
+// src/BVH.cpp:19-64 step by step, including the in-place sort of the caller's
+// vector.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rtr.h"
+
+#define MY_PI 3.1415926  // include/Global.h:4
+
+// ---- include/Vector.h ----
+class Vector2f {
+ public:
+  float x, y;
+  Vector2f() : x(0), y(0) {}
+  Vector2f(float v) : x(v), y(v) {}
+  Vector2f(float _x, float _y) : x(_x), y(_y) {}
+};
+
+class Vector3f {
+ public:
+  float x, y, z;
+  Vector3f() : x(0), y(0), z(0) {}
+  Vector3f(float v) : x(v), y(v), z(v) {}
+  Vector3f(float _x, float _y, float _z) : x(_x), y(_y), z(_z) {}
+  Vector3f operator+(const Vector3f &o) const { return Vector3f(x + o.x, y + o.y, z + o.z); }
+  Vector3f operator-(const Vector3f &o) const { return Vector3f(x - o.x, y - o.y, z - o.z); }
+  Vector3f operator-() const { return Vector3f(-x, -y, -z); }
+  Vector3f operator*(float n) const { return Vector3f(x * n, y * n, z * n); }
+  Vector3f operator*(const Vector3f &o) const { return Vector3f(x * o.x, y * o.y, z * o.z); }
+  Vector3f operator/(float n) const { return Vector3f(x / n, y / n, z / n); }
+  friend Vector3f operator*(float n, const Vector3f &v) { return Vector3f(n * v.x, n * v.y, n * v.z); }
+  float getLen() const;
+  float norm() const { return x * x + y * y + z * z; }  // squared length, include/Vector.h:82
+  Vector3f normalize() const;
+};
+
+namespace vec {
+float dotProduct(const Vector3f &a, const Vector3f &b);
+Vector3f crossProduct(const Vector3f &a, const Vector3f &b);
+}  // namespace vec
+
+// ---- include/Ray.h, include/Intersection.h ----
+struct Ray {
+  Vector3f startPos, dir;
+  Ray(Vector3f s, Vector3f d) : startPos(s), dir(d) {}
+};
+
+class Object;
+struct Intersection {
+  bool hit = false;
+  float distance = 0;
+  Vector3f postion;  // (sic) the reference's spelling
+  Vector3f normal;
+  Vector2f textureCoord;
+  Object *object = nullptr;
+};
+
+// ---- include/Bound3.h ----
+class Bound3 {
+ public:
+  Vector3f min, max;
+  Bound3();  // empty box: min = +FLT_MAX, max = lowest
+  Bound3(Vector3f lo, Vector3f hi) : min(lo), max(hi) {}
+  Bound3 &merge(const Bound3 &b);
+  Vector3f getCenterPos() const;
+};
+
+// ---- include/Material.h ----
+enum MaterialType { DIFFUSE, SPECULAR, MICROFACET };
+
+class Material {
+  MaterialType type;
+  Vector3f emission, kd, ks;
+  float ior, specularExponent, roughness;
+
+ public:
+  Material(MaterialType _type, Vector3f _emission, Vector3f _kd = Vector3f(0),
+           Vector3f _ks = Vector3f(0), float _ior = 1e-5, float _roughness = 1e-5,
+           float _specularExponent = 32);
+  MaterialType getMaterialType() const { return type; }
+  bool hasEmission() const;
+  Vector3f getEmission() const { return emission; }
+  Vector3f getKd() const { return kd; }
+  Vector3f getKs() const { return ks; }
+  float getIor() const { return ior; }
+  float getRoughness() const { return roughness; }
+  float getSpecularExponent() const { return specularExponent; }
+};
+
+// ---- include/Object.h ----
+class Object {
+ protected:
+  Material *material;
+  Bound3 bound;
+  float area = 0;
+
+ public:
+  enum Kind { SPHERE, TRIANGLE, MESH };
+  explicit Object(Material *m) : material(m) {}
+  virtual ~Object() {}
+  const Material *getMaterial() const { return material; }
+  Bound3 getBound() const { return bound; }
+  virtual float getArea() const { return area; }
+  virtual Kind kind() const = 0;
+};
+
+// ---- include/BVH.h ----
+struct BVHNode {
+  Bound3 bound;
+  Object *object = nullptr;
+  BVHNode *left = nullptr, *right = nullptr;
+};
+
+class BVH {
+  BVHNode *root = nullptr;
+  static BVHNode *build(std::vector<Object *> &objs);
+  static void destroy(BVHNode *n);
+
+ public:
+  BVH() {}
+  ~BVH() { destroy(root); }
+  BVH(const BVH &) = delete;
+  BVH &operator=(const BVH &) = delete;
+  // sorts objs in place like the reference does (src/BVH.cpp:42-55)
+  void buildBVH(std::vector<Object *> &objs);
+  Bound3 getBound() const { return root->bound; }
+  const BVHNode *getRoot() const { return root; }
+};
+
+// ---- include/Sphere.h ----
+class Sphere : public Object {
+  Vector3f center;
+  float radius;
+
+ public:
+  Sphere(Material *_material, Vector3f _center, float _radius);
+  Kind kind() const override { return SPHERE; }
+  Vector3f getCenter() const { return center; }
+  float getRadius() const { return radius; }
+};
+
+// ---- include/Trangle.h ----
+class Trangle : public Object {
+  Vector3f p0, p1, p2, normal;
+  Vector2f uv0, uv1, uv2;
+
+ public:
+  int indexInMesh = 0;  // position of this triangle's index triple in its mesh
+  Trangle(Material *_material, Vector3f _p0, Vector3f _p1, Vector3f _p2, Vector3f _normal,
+          Vector2f _uv0, Vector2f _uv1, Vector2f _uv2);
+  Kind kind() const override { return TRIANGLE; }
+  const Vector3f &P0() const { return p0; }
+  const Vector3f &P1() const { return p1; }
+  const Vector3f &P2() const { return p2; }
+  const Vector3f &getNormal() const { return normal; }
+};
+
+class TrangleMesh : public Object {
+  std::vector<Object *> trangles;  // re-ordered by the BVH build, like the reference's
+  BVH *bvh;
+
+ public:
+  TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
+              std::vector<unsigned int> *_posIndices, std::vector<Vector3f> *_normals = nullptr,
+              std::vector<Vector2f> *_textureCoords = nullptr);
+  ~TrangleMesh() override;
+  TrangleMesh(const TrangleMesh &) = delete;
+  TrangleMesh &operator=(const TrangleMesh &) = delete;
+  Kind kind() const override { return MESH; }
+  size_t numTrangles() const { return trangles.size(); }
+  const BVH *getBVH() const { return bvh; }
+};
+
+// ---- include/Scene.h ----
+struct Camera {
+  Vector3f position, frontDir, upDir;
+  float fov;
+  Camera(Vector3f p, Vector3f f, Vector3f u, float _fov) : position(p), frontDir(f), upDir(u), fov(_fov) {}
+};
+
+// The arrays of rtr_scene_desc, owned.
+struct FlatScene {
+  std::vector<float> node_bmin[3], node_bmax[3];
+  std::vector<int32_t> node_left, node_right, node_prim;
+  std::vector<int32_t> prim_kind, prim_index, prim_material;
+  std::vector<float> tri_p0[3], tri_p1[3], tri_p2[3], tri_n[3], tri_area;
+  std::vector<float> sph_c[3], sph_r, sph_area;
+  std::vector<int32_t> mat_kind;
+  std::vector<float> mat_emission[3], mat_kd[3], mat_ks[3], mat_ior, mat_roughness;
+  std::vector<int32_t> light_kind, light_prim, light_tri_begin, light_tris;
+  std::vector<float> light_area;
+  std::vector<Object *> prim_object;  // prim id -> Sphere* / Trangle*
+  rtr_scene_desc desc() const;
+};
+
+class Scene {
+  Camera *camera;
+  std::vector<Object *> objects;   // re-ordered by rebuildBVH, like the reference's
+  std::vector<Object *> addOrder;  // objects in addObject order: defines prim ids
+  std::vector<Object *> lights;
+  BVH *bvh;
+  rtr_scene *device = nullptr;
+  FlatScene flat;
+  int deviceIndex = 0;
+  bool flatValid = false;
+
+ public:
+  explicit Scene(Camera *_camera);
+  ~Scene();
+  Scene(const Scene &) = delete;
+  Scene &operator=(const Scene &) = delete;
+
+  const Camera *getCamera() const { return camera; }
+  void addObject(Object *obj);
+  void rebuildBVH();
+  // Scene::intersect of the reference, answered by the device (one-ray batch)
+  Intersection intersect(const Ray &ray);
+  // many rays at once: prim ids (-1 = miss) and distances; pos/nrm optional (n*3)
+  void intersectBatch(const float *org_xyz, const float *dir_xyz, size_t n, int32_t *prim_id,
+                      float *t, float *pos_xyz = nullptr, float *nrm_xyz = nullptr);
+
+  void setDevice(int index);
+  const FlatScene &flatten();  // (re)built after rebuildBVH
+  rtr_scene *deviceScene();    // uploaded on first use; throws if no device
+  const std::vector<Object *> &getLights() const { return lights; }
+};
+
+// ---- include/Render.h ----
+enum class RenderType { PathTracing };
+
+struct RenderOptions {  // what the reference hard-codes, see rtr_render_params
+  uint32_t seed = 0;
+  int max_depth = 0;
+  float rr_prob = 0;
+  int chunk_spp = 0, pool_size = 0;
+  int part_index = 0, part_count = 1, tile_cols = 8;
+  bool profile = false;
+};
+
+class Render {
+  std::vector<Vector3f> *buffer = nullptr;
+  rtr_stats lastStats{};
+
+ public:
+  RenderOptions options;
+  Render() {}
+  ~Render() { delete buffer; }
+  // src/Render.cpp:632-694: renders into the internal buffer (index i*height+j)
+  // and writes <fileName>.ppm unless fileName is empty.
+  void renderPathTracing(Scene &scene, const unsigned int &imageWidth,
+                         const unsigned int &imageHeight, const unsigned int &spp,
+                         std::string fileName);
+  void render(Scene &scene, const unsigned int &imageWidth, const unsigned int &imageHeight,
+              const unsigned int &spp, std::string fileName, RenderType type);
+  const std::vector<Vector3f> &getBuffer() const { return *buffer; }
+  const rtr_stats &getStats() const { return lastStats; }
+  // Render::saveFile, src/Render.cpp:3-21 (public here so tools can reuse it)
+  static void saveFile(const std::vector<Vector3f> &pixels, const std::string &fileName,
+                       unsigned int height, unsigned int width);
+};
