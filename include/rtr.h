@@ -138,7 +138,7 @@ typedef struct rtr_render_params {
   int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: auto */
   int32_t pool_size;  /* concurrent paths; <=0: auto */
   int32_t part_index, part_count, tile_cols;
-  int32_t profile;    /* 1: time every kernel kind with events (slower) */
+  int32_t profile;    /* 1: bracket every kernel with events on the launch stream */
 } rtr_render_params;
 
 typedef struct rtr_stats {

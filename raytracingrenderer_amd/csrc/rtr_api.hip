@@ -602,47 +602,67 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
               ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr};
   Counters *cnt = ws.counters.ptr;
 
+  // profile=1: every kernel is bracketed by a pair of events on the launch stream;
+  // elapsed times are read back only after a synchronisation the render needs
+  // anyway, so profiling adds event records but no extra waits.
   const bool prof = prm->profile != 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double ms_trace = 0, ms_logic = 0, ms_other = 0;
-  if (prof) {
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-  }
-  auto timed = [&](double &acc, auto &&launch) -> hipError_t {
-    if (prof) (void)hipEventRecord(ev0, st);
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> spans;      // recorded, not yet read
+  std::vector<Span> free_spans; // reusable
+  double ms_kind[3] = {0, 0, 0};  // 0 trace, 1 logic, 2 other
+  auto harvest = [&]() {
+    for (Span &sp : spans) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) ms_kind[sp.kind] += ms;
+      free_spans.push_back(sp);
+    }
+    spans.clear();
+  };
+  auto timed = [&](int kind, auto &&launch) -> hipError_t {
+    Span sp{nullptr, nullptr, kind};
+    if (prof) {
+      if (!free_spans.empty()) {
+        sp = free_spans.back();
+        sp.kind = kind;
+        free_spans.pop_back();
+      } else {
+        hipError_t e = hipEventCreate(&sp.a);
+        if (e == hipSuccess) e = hipEventCreate(&sp.b);
+        if (e != hipSuccess) return e;
+      }
+      (void)hipEventRecord(sp.a, st);
+    }
     launch();
     hipError_t e = hipGetLastError();
-    if (prof && e == hipSuccess) {
-      (void)hipEventRecord(ev1, st);
-      (void)hipEventSynchronize(ev1);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, ev0, ev1);
-      acc += ms;
+    if (prof) {
+      (void)hipEventRecord(sp.b, st);
+      spans.push_back(sp);
     }
     return e;
   };
+  const int kTrace = 0, kLogic = 1, kOther = 2;
 
   HIP_TRY(hipMemcpyAsync(ws.cols.ptr, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), st));
   HIP_TRY(hipMemsetAsync(ws.pool[7].ptr, 0, pool * sizeof(float4), st));  // flags = 0: no unit
   uint64_t trace_launches = 0;
-  HIP_TRY(timed(ms_other, [&] {
+  HIP_TRY(timed(kOther, [&] {
     hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, cs,
                        ws.cols.ptr, ws.pix_dir.ptr);
   }));
-  HIP_TRY(timed(ms_trace, [&] {
+  HIP_TRY(timed(kTrace, [&] {
     hipLaunchKernelGGL(k_trace_primary, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, s->ds, cs,
                        ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
   }));
   trace_launches++;
-  HIP_TRY(timed(ms_other, [&] {
+  HIP_TRY(timed(kOther, [&] {
     hipLaunchKernelGGL(k_classify, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, s->ds,
                        s->mats.ptr, cs, ws.pix_dir.ptr, ws.pix_hit.ptr, pc, ws.shade_list.ptr, cnt,
                        ws.partial.ptr);
   }));
   HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  harvest();
   const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
 
   uint64_t iters = 0;
@@ -651,12 +671,12 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
-        HIP_TRY(timed(ms_logic, [&] {
+        HIP_TRY(timed(kLogic, [&] {
           hipLaunchKernelGGL(k_logic, dim3(blocks_for(pool)), dim3(kBlock), 0, st, a, s->ds, s->dl,
                              s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, cnt,
                              ws.partial.ptr, parity);
         }));
-        HIP_TRY(timed(ms_trace, [&] {
+        HIP_TRY(timed(kTrace, [&] {
           hipLaunchKernelGGL(k_trace_queue, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st, s->ds,
                              pp, ws.queue.ptr, cnt, parity);
         }));
@@ -665,18 +685,20 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       }
       HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
+      harvest();
       if (ws.host_counters->units_done >= n_units) break;
       if (iters > (uint64_t)1 << 40) return fail(RTR_ERR_DEVICE, "render did not terminate");
     }
   }
-  HIP_TRY(timed(ms_other, [&] {
+  HIP_TRY(timed(kOther, [&] {
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a,
                        ws.partial.ptr, d_rgb);
   }));
   HIP_TRY(hipStreamSynchronize(st));
-  if (prof) {
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+  harvest();
+  for (Span &sp : free_spans) {
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
   }
   if (stats) {
     stats->samples = (uint64_t)a.n_pix * a.spp;
@@ -686,9 +708,9 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     stats->chunk_spp = a.chunk_spp;
     stats->pool_size = a.pool;
     stats->n_columns = a.n_cols;
-    stats->ms_trace = ms_trace;
-    stats->ms_logic = ms_logic;
-    stats->ms_other = ms_other;
+    stats->ms_trace = ms_kind[kTrace];
+    stats->ms_logic = ms_kind[kLogic];
+    stats->ms_other = ms_kind[kOther];
     stats->trace_launches = trace_launches;
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
