@@ -578,7 +578,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
   size_t pool = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
   if (pool > max_units) pool = max_units;
-  pool = (pool + kBlock - 1) / kBlock * kBlock;
+  pool = (pool + kLogicBlock - 1) / kLogicBlock * kLogicBlock;
   if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
   a.pool = (int)pool;
   CameraSetup cs = camera_setup(*cam, a.H);
@@ -672,7 +672,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
         HIP_TRY(timed(kLogic, [&] {
-          hipLaunchKernelGGL(k_logic, dim3(blocks_for(pool)), dim3(kBlock), 0, st, a, s->ds, s->dl,
+          hipLaunchKernelGGL(k_logic, dim3((unsigned)((pool + kLogicBlock - 1) / kLogicBlock)), dim3(kLogicBlock), 0, st, a, s->ds, s->dl,
                              s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, cnt,
                              ws.partial.ptr, parity);
         }));
@@ -702,7 +702,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   }
   if (stats) {
     stats->samples = (uint64_t)a.n_pix * a.spp;
-    stats->rays = ws.host_counters->rays + (uint64_t)a.n_pix;
+    stats->rays = ws.host_counters->rays + (uint64_t)a.n_pix;  // queue rays + primary rays
     stats->vertices = ws.host_counters->vertices;
     stats->iterations = iters;
     stats->chunk_spp = a.chunk_spp;

@@ -19,6 +19,8 @@
 namespace rtr {
 
 constexpr int kBlock = 256;
+constexpr int kLogicBlock = 1024;  // 16 waves share one set of global atomics
+constexpr int kLogicWaves = kLogicBlock / 64;
 
 struct CameraSetup {  // src/Render.cpp:639-649, computed on the host
   V3 eye, front, hstep, vstep;
@@ -48,14 +50,20 @@ struct PathPool {
 
 enum : uint32_t { kLive = 1u, kHasShadow = 2u, kHasExt = 4u, kHasUnit = 8u };
 
-struct Counters {
-  unsigned int qcount[2];
-  unsigned int next_unit;
+// Each hot counter sits on its own 128-byte line: they are hit by returning
+// atomics from every workgroup, and sharing a line would serialise them.
+struct alignas(128) Counters {
+  unsigned int qcount[2];  // rays queued by iteration parity
+  unsigned int n_shade;    // pixels that need sampling
+  unsigned int pad0[29];
+  unsigned int next_unit;  // work-unit dispenser
+  unsigned int pad1[31];
   unsigned int units_done;
-  unsigned int n_shade;
-  unsigned int pad;
-  unsigned long long rays;
+  unsigned int pad2[31];
   unsigned long long vertices;
+  unsigned long long pad3[15];
+  unsigned long long rays;  // written by one thread per traversal launch
+  unsigned long long pad4[15];
 };
 
 struct RenderArgs {
@@ -115,7 +123,9 @@ __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
               const Counters *__restrict__ cnt, int parity) {
   unsigned i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= cnt->qcount[parity]) return;
+  const unsigned nq = cnt->qcount[parity];
+  if (i == 0) const_cast<Counters *>(cnt)->rays += nq;  // the only writer of this word
+  if (i >= nq) return;
   uint32_t e = queue[i];
   uint32_t slot = e & 0x7fffffffu;
   bool ext = e >> 31;
@@ -182,12 +192,19 @@ k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats
 }
 
 // ---- one wavefront iteration of path logic ----
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kLogicBlock)
 k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
         PixelCache pc, PathPool p, const uint32_t *__restrict__ shade_list,
         uint32_t *__restrict__ queue, Counters *__restrict__ cnt, float4 *__restrict__ partial,
         int parity) {
-  const int slot = blockIdx.x * kBlock + threadIdx.x;
+  // Counts are first combined across the workgroup's 16 waves in LDS so that a
+  // workgroup issues one returning atomic per counter instead of one per wave:
+  // with a million slots, per-wave atomics on a handful of words were the
+  // kernel's whole run time.
+  __shared__ unsigned s_count[5][kLogicWaves];
+  __shared__ unsigned s_base[2];
+  const int slot = blockIdx.x * kLogicBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6;
   const bool in_range = slot < a.pool;
   if (slot == 0) cnt->qcount[parity ^ 1] = 0;
 
@@ -265,27 +282,35 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   {
     unsigned long long m_fin = __ballot(unit_finished);
     unsigned long long m_want = __ballot(want_unit);
-    if (m_fin | m_want) {
-      int leader = __ffsll((long long)(m_fin | m_want)) - 1;
+    if (lane_id() == 0) {
+      s_count[0][wave] = (unsigned)__popcll(m_fin);
+      s_count[1][wave] = (unsigned)__popcll(m_want);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned fin = 0, want = 0;
+      for (int w = 0; w < kLogicWaves; w++) { fin += s_count[0][w]; want += s_count[1][w]; }
+      if (fin) atomicAdd(&cnt->units_done, fin);
       unsigned base = n_units;
-      if ((int)lane_id() == leader) {
-        if (m_fin) atomicAdd(&cnt->units_done, (unsigned)__popcll(m_fin));
-        if (m_want && *(volatile unsigned *)&cnt->next_unit < n_units)
-          base = atomicAdd(&cnt->next_unit, (unsigned)__popcll(m_want));
-      }
-      base = __shfl(base, leader);
-      if (want_unit) {
-        unsigned u = base + (unsigned)__popcll(m_want & lanes_below());
-        if (base < n_units && u < n_units) {
-          unsigned ns = cnt->n_shade;
-          chunk = u / ns;
-          lp = shade_list[u - chunk * ns];
-          k = chunk * (uint32_t)a.chunk_spp;
-          k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
-          acc = mk(0, 0, 0);
-          gpix = wbits(pc.wi[lp]);
-          flags |= kHasUnit;
-        }
+      if (want && *(volatile unsigned *)&cnt->next_unit < n_units)
+        base = atomicAdd(&cnt->next_unit, want);
+      s_base[0] = base;
+    }
+    __syncthreads();
+    if (want_unit) {
+      unsigned before = 0;
+      for (int w = 0; w < wave; w++) before += s_count[1][w];
+      const unsigned base = s_base[0];
+      unsigned u = base + before + (unsigned)__popcll(m_want & lanes_below());
+      if (base < n_units && u < n_units) {
+        unsigned ns = cnt->n_shade;
+        chunk = u / ns;
+        lp = shade_list[u - chunk * ns];
+        k = chunk * (uint32_t)a.chunk_spp;
+        k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+        acc = mk(0, 0, 0);
+        gpix = wbits(pc.wi[lp]);
+        flags |= kHasUnit;
       }
     }
   }
@@ -350,20 +375,37 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     p.Hh[slot] = pack(mk(0, 0, 0), 0u);
   }
 
-  // 64-wide compaction of the emitted rays into the queue
+  // compaction of the emitted rays into the queue: 64-wide ballots give each
+  // lane its rank inside the wave, LDS combines the waves, one atomic per
+  // workgroup reserves the range.  A workgroup's shadow rays come first, then
+  // its extension rays, so traversal waves are mostly of one kind.
   unsigned long long ms = __ballot(has_shadow), me = __ballot(has_ext), ml = __ballot(live);
-  if (ml) {
-    int leader = __ffsll((long long)ml) - 1;
-    unsigned ns = (unsigned)__popcll(ms), ne = (unsigned)__popcll(me);
+  if (lane_id() == 0) {
+    s_count[2][wave] = (unsigned)__popcll(ms);
+    s_count[3][wave] = (unsigned)__popcll(me);
+    s_count[4][wave] = (unsigned)__popcll(ml);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned ns = 0, ne = 0, nl = 0;
+    for (int w = 0; w < kLogicWaves; w++) { ns += s_count[2][w]; ne += s_count[3][w]; nl += s_count[4][w]; }
     unsigned base = 0;
-    if ((int)lane_id() == leader) {
-      base = atomicAdd(&cnt->qcount[parity], ns + ne);
-      atomicAdd(&cnt->rays, (unsigned long long)(ns + ne));
-      atomicAdd(&cnt->vertices, (unsigned long long)__popcll(ml));
+    if (ns + ne) base = atomicAdd(&cnt->qcount[parity], ns + ne);
+    if (nl) atomicAdd(&cnt->vertices, (unsigned long long)nl);
+    s_base[1] = base;
+  }
+  __syncthreads();
+  if (has_shadow || has_ext) {
+    unsigned sh_before = 0, ext_before = 0, sh_total = 0;
+    for (int w = 0; w < kLogicWaves; w++) {
+      unsigned cs = s_count[2][w];
+      if (w < wave) { sh_before += cs; ext_before += s_count[3][w]; }
+      sh_total += cs;
     }
-    base = __shfl(base, leader);
-    if (has_shadow) queue[base + __popcll(ms & lanes_below())] = (uint32_t)slot;
-    if (has_ext) queue[base + ns + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
+    const unsigned base = s_base[1];
+    if (has_shadow) queue[base + sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
+    if (has_ext)
+      queue[base + sh_total + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
   }
 }
 
