@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors in this directory from the REFERENCE itself.
+
+Needs oracle/_ref/libref.so (the reference's own sources compiled by
+oracle/Makefile), so it only runs where the reference checkout exists.  The
+outputs are data -- inputs and the reference's outputs -- never source text:
+
+  bvh_default.npz        spliced tree of the default scene (bounds, children, prim ids),
+                         top-level leaf order, object areas
+  rays_default.npz       ray batch (primary, secondary, interior, adversarial) and the
+                         reference's (prim id, distance, position, normal)
+  materials_default.npz  Material::eval / pdf tables, and Material::sample outputs together
+                         with the mt19937 draws that produced them
+  lights_default.npz     Scene::samplingLight outputs + draws (default scene and a
+                         multi-light scene with an emissive mesh)
+  paths_default.npz      Render::pathTracing radiance for (ray, seed) pairs + the draws
+  ref_render_128x128_4096spp.npy        Render::renderPathTracing float buffer
+  ref_render_128x128_4096spp_noise.npy  RMSE between two independent such renders
+
+Run:  python tests/golden/make_golden.py [--skip-render]
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _rays  # noqa: E402
+from _oracle import Oracle, Ref, default_scene_spec  # noqa: E402
+
+f32 = np.float32
+
+
+def multi_light_spec():
+    spec = default_scene_spec()
+    plate = np.array([[224, 20, -288], [288, 20, -288], [224, 20, -224], [288, 20, -224]], f32)
+    spec["objects"] = [("sphere", "light", (100, 300, -200), 15)] + spec["objects"] + \
+                      [("mesh", "light", plate, [0, 1, 2, 3, 2, 1])]
+    return spec
+
+
+def main():
+    R = Ref()
+    O = Oracle()  # only used to generate primary-ray INPUTS (camera set-up)
+    sr = R.default_scene()
+    so = O.default_scene()
+
+    lo, hi, child, prim = sr.flatten()
+    np.savez_compressed(os.path.join(HERE, "bvh_default.npz"), bmin=lo, bmax=hi, child=child,
+                        prim=prim, top_leaf_order=sr.top_leaf_order(),
+                        areas=np.array([sr.object_area(o) for o in range(14)], f32))
+
+    org, d = _rays.default_batch(O, so, n_interior=6000, prim_step=16)
+    p, t, pos, nrm = sr.intersect(org, d)
+    np.savez_compressed(os.path.join(HERE, "rays_default.npz"), org=org, dir=d, prim=p, t=t,
+                        pos=pos, nrm=nrm)
+
+    rng = np.random.default_rng(100)
+    n = 3000
+    wi, wo, nn = [rng.normal(size=(n, 3)).astype(f32) for _ in range(3)]
+    nu = nn / np.linalg.norm(nn, axis=1, keepdims=True)
+    wiu = wi / np.linalg.norm(wi, axis=1, keepdims=True)
+    wo[: n // 4] = (2 * (nu * wiu).sum(1, keepdims=True) * nu - wiu)[: n // 4].astype(f32)
+    out = dict(wi=wi, wo=wo, n=nn, n_unit=nu.astype(f32))
+    ns = 1000
+    out["sample_u"] = np.stack([R.draws(5000 + k, 2) for k in range(ns)])
+    for m in ["white", "red", "spec", "micro", "light"]:
+        out["eval_" + m] = sr.material_eval(m, wi, wo, nn)
+        out["pdf_" + m] = sr.material_pdf(m, wi, wo, nn)
+        out["sample_" + m] = R.material_sample(sr, m, wi[:ns], nu.astype(f32)[:ns], seed=5000)
+    np.savez_compressed(os.path.join(HERE, "materials_default.npz"), **out)
+
+    def light_table(scene, seeds, ndraw):
+        rows = dict(u=[], pos=[], nrm=[], pdf=[], prim=[])
+        for s in seeds:
+            po, no, pd, pr = R.sample_light(scene, s)
+            rows["u"].append(R.draws(s, ndraw))
+            rows["pos"].append(po)
+            rows["nrm"].append(no)
+            rows["pdf"].append(pd)
+            rows["prim"].append(pr)
+        return {k: np.array(v) for k, v in rows.items()}
+    a = light_table(sr, range(500), 8)
+    b = light_table(R.build_scene(multi_light_spec()), range(500), 16)
+    np.savez_compressed(os.path.join(HERE, "lights_default.npz"),
+                        **{"single_" + k: v for k, v in a.items()},
+                        **{"multi_" + k: v for k, v in b.items()})
+
+    po, pd = _rays.primary_rays(O, so, 784, 784, 23)
+    rgb, draws, keep_o, keep_d = [], [], [], []
+    ND = 384
+    for k in range(len(po)):
+        seed = 9000 + k
+        c = R.path_trace(sr, po[k], pd[k], seed)
+        u = R.draws(seed, ND)
+        # keep the pair only if the path provably consumed fewer than ND draws
+        got, used = O.path_trace_u(so, po[k], pd[k], u)
+        if used <= ND:
+            rgb.append(c)
+            draws.append(u)
+            keep_o.append(po[k])
+            keep_d.append(pd[k])
+    np.savez_compressed(os.path.join(HERE, "paths_default.npz"), org=np.array(keep_o, f32),
+                        dir=np.array(keep_d, f32), u=np.array(draws, f32), rgb=np.array(rgb, f32))
+    print("paths kept:", len(rgb), "of", len(po))
+
+    if "--skip-render" not in sys.argv:
+        a = R.render(sr, 128, 128, 4096, "/tmp/golden_a")
+        b = R.render(sr, 128, 128, 4096, "/tmp/golden_b")
+        np.save(os.path.join(HERE, "ref_render_128x128_4096spp.npy"), a)
+        np.save(os.path.join(HERE, "ref_render_128x128_4096spp_noise.npy"),
+                np.array(np.sqrt(((a - b) ** 2).mean()), f32))
+        lum = lambda x: float((x * np.array([0.2126, 0.7152, 0.0722], f32)).sum(1).mean())
+        print("render rmse between runs:", float(np.sqrt(((a - b) ** 2).mean())),
+              "lum", lum(a), lum(b))
+
+
+if __name__ == "__main__":
+    main()
