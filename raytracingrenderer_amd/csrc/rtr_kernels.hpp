@@ -93,12 +93,13 @@ __global__ void __launch_bounds__(kBlock)
 k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
             int32_t *__restrict__ prim, float *__restrict__ t, float *__restrict__ pos,
             float *__restrict__ nrm) {
+  __shared__ MergeStack stacks[kBlock / 64];
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
   V3 d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
   V3 dn = unit(d);
-  HitRec h = trace_closest(sc, o, d, dn);
+  HitRec h = trace_closest(sc, o, d, dn, stacks[threadIdx.x >> 6]);
   prim[i] = hit_prim(sc, h);
   t[i] = h.t;
   V3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
@@ -111,10 +112,11 @@ k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restri
 __global__ void __launch_bounds__(kBlock)
 k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir, int n,
                 float4 *__restrict__ hit) {
+  __shared__ MergeStack stacks[kBlock / 64];
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 d = xyz(dir[i]);
-  HitRec h = trace_closest(sc, cam.eye, d, unit(d));
+  HitRec h = trace_closest(sc, cam.eye, d, unit(d), stacks[threadIdx.x >> 6]);
   hit[i] = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
 }
 
@@ -122,6 +124,7 @@ k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir,
 __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
               const Counters *__restrict__ cnt, int parity) {
+  __shared__ MergeStack stacks[kBlock / 64];
   unsigned i = blockIdx.x * kBlock + threadIdx.x;
   const unsigned nq = cnt->qcount[parity];
   if (i == 0) const_cast<Counters *>(cnt)->rays += nq;  // the only writer of this word
@@ -131,7 +134,7 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
   bool ext = e >> 31;
   V3 o = xyz(p.A[slot]);
   V3 d = xyz(ext ? p.K[slot] : p.J[slot]);
-  HitRec h = trace_closest(sc, o, d, unit(d));
+  HitRec h = trace_closest(sc, o, d, unit(d), stacks[threadIdx.x >> 6]);
   float4 out = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
   if (ext) p.he[slot] = out; else p.hs[slot] = out;
 }

@@ -114,22 +114,30 @@ RTR_DEV bool hit_leaf(const DeviceScene &sc, int leaf, V3 o, V3 dir, V3 dn, HitR
   return hit_triangle(sc, row, o, dir, dn, h.t, h.b1, h.b2);
 }
 
+// Stack of the literal merge-tree evaluation below: one per wave, in LDS.  It is
+// only touched by rays that saw a NaN hit distance, one lane at a time, so it
+// costs no registers and no scratch memory on the common path.
+struct MergeStack {
+  int node[kMaxDepth];
+  float lt[kMaxDepth], lb1[kMaxDepth], lb2[kMaxDepth];
+  int lleaf[kMaxDepth];
+  unsigned char phase[kMaxDepth];
+};
+
 // Literal evaluation of the reference's merge tree (src/BVH.cpp:66-80) with an
 // explicit stack; only used for rays on which a NaN hit distance was seen.
-__device__ __noinline__ HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn) {
+RTR_DEV HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack &st) {
   // frame: node index, phase (0 = enter, 1 = left done, 2 = right done), left result
-  int node[kMaxDepth];
-  unsigned char phase[kMaxDepth];
-  HitRec left[kMaxDepth];
   int sp = 0;
-  node[0] = 0;
-  phase[0] = 0;
+  st.node[0] = 0;
+  st.phase[0] = 0;
   HitRec ret;
   ret.leaf = -1;
   ret.t = 0; ret.b1 = 0; ret.b2 = 0;
   while (sp >= 0) {
-    int i = node[sp];
-    if (phase[sp] == 0) {
+    int i = st.node[sp];
+    int ph = st.phase[sp];
+    if (ph == 0) {
       float4 lo = sc.nodes[2 * i], hi = sc.nodes[2 * i + 1];
       int leaf = (int)wbits(hi);
       ret.leaf = -1;
@@ -140,19 +148,19 @@ __device__ __noinline__ HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V
         sp--;
         continue;
       }
-      phase[sp] = 1;
       if (sp + 1 >= kMaxDepth) { ret.leaf = -1; return ret; }  // rejected at scene creation
-      node[sp + 1] = i + 1;
-      phase[sp + 1] = 0;
+      st.phase[sp] = 1;
+      st.node[sp + 1] = i + 1;
+      st.phase[sp + 1] = 0;
       sp++;
-    } else if (phase[sp] == 1) {
-      left[sp] = ret;
-      phase[sp] = 2;
-      node[sp + 1] = (int)wbits(sc.nodes[2 * (i + 1)]);  // right child = skip of the left child
-      phase[sp + 1] = 0;
+    } else if (ph == 1) {
+      st.lt[sp] = ret.t; st.lb1[sp] = ret.b1; st.lb2[sp] = ret.b2; st.lleaf[sp] = ret.leaf;
+      st.phase[sp] = 2;
+      st.node[sp + 1] = (int)wbits(sc.nodes[2 * (i + 1)]);  // right child = skip of the left child
+      st.phase[sp + 1] = 0;
       sp++;
     } else {
-      HitRec l = left[sp], r = ret, out;
+      HitRec l{st.lt[sp], st.lb1[sp], st.lb2[sp], st.lleaf[sp]}, r = ret, out;
       out.leaf = -1; out.t = 0; out.b1 = 0; out.b2 = 0;
       out = (l.leaf >= 0) ? l : out;
       out = (r.leaf >= 0) ? ((out.leaf >= 0) ? ((out.t < r.t) ? out : r) : r) : out;
@@ -164,7 +172,7 @@ __device__ __noinline__ HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V
 }
 
 // Scene::intersect for one ray.
-RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn) {
+RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack &wave_stack) {
   HitRec best;
   best.leaf = -1;
   best.t = 0; best.b1 = 0; best.b2 = 0;
@@ -191,7 +199,13 @@ RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn) {
       i = skip;
     }
   }
-  if (saw_nan) best = trace_tree(sc, o, dir, dn);
+  // rare: evaluate the merge tree literally, one lane of the wave at a time
+  unsigned long long need = __ballot(saw_nan);
+  while (need) {
+    int l = __ffsll((long long)need) - 1;
+    if ((int)(threadIdx.x & 63u) == l) best = trace_tree(sc, o, dir, dn, wave_stack);
+    need &= need - 1;
+  }
   return best;
 }
 
