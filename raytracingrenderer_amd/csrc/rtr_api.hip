@@ -78,6 +78,7 @@ struct rtr_scene {
   DeviceScene ds{};
   DeviceLights dl{};
   int n_materials = 0;
+  bool lds_geometry = false;  // scene small enough for the kernels to stage it in LDS
   Workspace ws;
   // scratch for the host-pointer entry points
   DevBuf<float> io_f[5];
@@ -223,6 +224,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
 
   // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
   std::vector<float4> nodes;
+  bool fast_planes = true;  // precondition of the certified box filter (rtr_trace.hpp)
   if (d->n_nodes > 0) {
     const int n = d->n_nodes;
     std::vector<int32_t> order;  // new index -> old index
@@ -270,6 +272,11 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
       float4 lo, hi;
       lo.x = d->node_bmin[0][o]; lo.y = d->node_bmin[1][o]; lo.z = d->node_bmin[2][o];
       hi.x = d->node_bmax[0][o]; hi.y = d->node_bmax[1][o]; hi.z = d->node_bmax[2][o];
+      for (float v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) {
+        float m = fabsf(v);
+        if (!(m == 0.0f || (m >= 9.094947017729282e-13f && m <= 1.099511627776e12f)))
+          fast_planes = false;
+      }
       memcpy(&lo.w, &skip, 4);
       memcpy(&hi.w, &payload, 4);
       nodes[2 * (size_t)i] = lo;
@@ -375,6 +382,10 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.prim_material = s->prim_material.ptr;
   s->ds.n_nodes = d->n_nodes;
   s->ds.n_prims = d->n_prims;
+  s->ds.fast_planes = fast_planes ? 1 : 0;
+  s->ds.n_tris = d->n_tris;
+  s->ds.n_sphs = d->n_spheres;
+  s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs;
   s->dl.light = s->lights.ptr;
   s->dl.light_tris = s->light_tris.ptr;
   s->dl.tri_area = s->tri_area.ptr;
@@ -406,8 +417,12 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
   if (!d_org || !d_dir || !d_prim || !d_t) return fail(RTR_ERR_INVALID, "null ray or result array");
   if (n > (size_t)0x7fffffff * kBlock) return fail(RTR_ERR_INVALID, "batch too large");
   DeviceGuard guard(s->device);
-  hipLaunchKernelGGL(k_trace_api, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, s->ds,
-                     d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
+  if (s->lds_geometry)
+    hipLaunchKernelGGL(k_trace_api<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
+  else
+    hipLaunchKernelGGL(k_trace_api<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
   HIP_TRY(hipGetLastError());
   return RTR_OK;
 }
@@ -651,8 +666,12 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
                        ws.cols.ptr, ws.pix_dir.ptr);
   }));
   HIP_TRY(timed(kTrace, [&] {
-    hipLaunchKernelGGL(k_trace_primary, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, s->ds, cs,
-                       ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
+    if (s->lds_geometry)
+      hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st,
+                         s->ds, cs, ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
+    else
+      hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st,
+                         s->ds, cs, ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
   }));
   trace_launches++;
   HIP_TRY(timed(kOther, [&] {
@@ -677,8 +696,12 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
                              ws.partial.ptr, parity);
         }));
         HIP_TRY(timed(kTrace, [&] {
-          hipLaunchKernelGGL(k_trace_queue, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st, s->ds,
-                             pp, ws.queue.ptr, cnt, parity);
+          if (s->lds_geometry)
+            hipLaunchKernelGGL(k_trace_queue<true>, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st,
+                               s->ds, pp, ws.queue.ptr, cnt, parity);
+          else
+            hipLaunchKernelGGL(k_trace_queue<false>, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st,
+                               s->ds, pp, ws.queue.ptr, cnt, parity);
         }));
         trace_launches++;
         iters++;

@@ -89,17 +89,35 @@ k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4
 }
 
 // ---- traversal over explicit ray arrays (the rtr_trace_closest entry point) ----
+// Closest hit from staged (LDS) or global geometry; kLds is chosen by the host
+// from the scene's size.
+template <bool kLds>
+RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, V3 o, V3 d, V3 dn,
+                         MergeStack &stack) {
+  if (kLds) {
+    LdsGeom g{lds.nodes, lds.tris, lds.sphs};
+    return trace_closest(g, sc.n_nodes, sc.fast_planes != 0, o, d, dn, stack);
+  }
+  return trace_closest(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, o, d, dn, stack);
+}
+
+template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
             int32_t *__restrict__ prim, float *__restrict__ t, float *__restrict__ pos,
             float *__restrict__ nrm) {
   __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ LdsScene lds;
+  if (kLds) {
+    stage_scene(sc, lds, threadIdx.x, kBlock);
+    __syncthreads();
+  }
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
   V3 d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
   V3 dn = unit(d);
-  HitRec h = trace_closest(sc, o, d, dn, stacks[threadIdx.x >> 6]);
+  HitRec h = trace_any<kLds>(sc, lds, o, d, dn, stacks[threadIdx.x >> 6]);
   prim[i] = hit_prim(sc, h);
   t[i] = h.t;
   V3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
@@ -109,32 +127,45 @@ k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restri
 }
 
 // ---- traversal of the primary rays (one per pixel, shared by all its samples) ----
+template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir, int n,
                 float4 *__restrict__ hit) {
   __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ LdsScene lds;
+  if (kLds) {
+    stage_scene(sc, lds, threadIdx.x, kBlock);
+    __syncthreads();
+  }
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 d = xyz(dir[i]);
-  HitRec h = trace_closest(sc, cam.eye, d, unit(d), stacks[threadIdx.x >> 6]);
+  HitRec h = trace_any<kLds>(sc, lds, cam.eye, d, unit(d), stacks[threadIdx.x >> 6]);
   hit[i] = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
 }
 
 // ---- traversal of the ray queue ----
+template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
               const Counters *__restrict__ cnt, int parity) {
   __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ LdsScene lds;
   unsigned i = blockIdx.x * kBlock + threadIdx.x;
   const unsigned nq = cnt->qcount[parity];
   if (i == 0) const_cast<Counters *>(cnt)->rays += nq;  // the only writer of this word
+  if (blockIdx.x * kBlock >= nq) return;  // whole workgroup has nothing to do
+  if (kLds) {
+    stage_scene(sc, lds, threadIdx.x, kBlock);
+    __syncthreads();
+  }
   if (i >= nq) return;
   uint32_t e = queue[i];
   uint32_t slot = e & 0x7fffffffu;
   bool ext = e >> 31;
   V3 o = xyz(p.A[slot]);
   V3 d = xyz(ext ? p.K[slot] : p.J[slot]);
-  HitRec h = trace_closest(sc, o, d, unit(d), stacks[threadIdx.x >> 6]);
+  HitRec h = trace_any<kLds>(sc, lds, o, d, unit(d), stacks[threadIdx.x >> 6]);
   float4 out = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
   if (ext) p.he[slot] = out; else p.hs[slot] = out;
 }

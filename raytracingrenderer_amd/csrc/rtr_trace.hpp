@@ -38,7 +38,29 @@ struct DeviceScene {
   const int32_t *prim_material;
   int32_t n_nodes;
   int32_t n_prims;
+  int32_t fast_planes;  // 1: every box plane is 0 or has magnitude in [2^-40, 2^40]
+  int32_t n_tris, n_sphs;
 };
+
+// Where traversal reads geometry from.  GlobalGeom gathers from HBM through the
+// caches; LdsGeom reads a copy the workgroup staged in LDS (scenes small enough
+// to fit: lower and steadier latency than the vector L1, which the streaming
+// path state keeps evicting).
+struct GlobalGeom {
+  const float4 *nodes, *tris, *sphs;
+  RTR_DEV float4 node_lo(int i) const { return nodes[2 * i]; }
+  RTR_DEV float4 node_hi(int i) const { return nodes[2 * i + 1]; }
+  RTR_DEV float4 tri(int row, int k) const { return tris[3 * row + k]; }
+  RTR_DEV float4 sph(int row) const { return sphs[row]; }
+};
+struct LdsGeom {
+  const float4 *nodes, *tris, *sphs;  // point into __shared__ arrays
+  RTR_DEV float4 node_lo(int i) const { return nodes[2 * i]; }
+  RTR_DEV float4 node_hi(int i) const { return nodes[2 * i + 1]; }
+  RTR_DEV float4 tri(int row, int k) const { return tris[3 * row + k]; }
+  RTR_DEV float4 sph(int row) const { return sphs[row]; }
+};
+RTR_DEV GlobalGeom global_geom(const DeviceScene &sc) { return GlobalGeom{sc.nodes, sc.tris, sc.sphs}; }
 
 struct HitRec {
   float t, b1, b2;
@@ -64,9 +86,10 @@ RTR_DEV bool slab(float4 lo, float4 hi, V3 o, V3 d) {
 
 // Trangle::intersect, src/Trangle.cpp:3-28.  `dir` is the ray direction as
 // given (used un-normalised by the back-face test, :5), `dn` its normalisation.
-RTR_DEV bool hit_triangle(const DeviceScene &sc, int row, V3 o, V3 dir, V3 dn, float &t,
-                          float &b1, float &b2) {
-  float4 q0 = sc.tris[3 * row], q1 = sc.tris[3 * row + 1], q2 = sc.tris[3 * row + 2];
+template <class Geom>
+RTR_DEV bool hit_triangle(const Geom &g, int row, V3 o, V3 dir, V3 dn, float &t, float &b1,
+                          float &b2) {
+  float4 q0 = g.tri(row, 0), q1 = g.tri(row, 1), q2 = g.tri(row, 2);
   V3 p0 = xyz(q0), p1 = xyz(q1), p2 = xyz(q2), n = mk(q0.w, q1.w, q2.w);
   if (dot(-dir, n) < 0) return false;
   V3 e1 = p1 - p0, e2 = p2 - p0, s = o - p0;
@@ -84,8 +107,9 @@ RTR_DEV bool hit_triangle(const DeviceScene &sc, int row, V3 o, V3 dir, V3 dn, f
 }
 
 // Sphere::intersect, src/Sphere.cpp:3-39.
-RTR_DEV bool hit_sphere(const DeviceScene &sc, int row, V3 org, V3 d, float &t) {
-  float4 q = sc.sphs[row];
+template <class Geom>
+RTR_DEV bool hit_sphere(const Geom &g, int row, V3 org, V3 d, float &t) {
+  float4 q = g.sph(row);
   V3 c = xyz(q);
   float r = q.w;
   V3 o = org - c;
@@ -103,15 +127,16 @@ RTR_DEV bool hit_sphere(const DeviceScene &sc, int row, V3 org, V3 d, float &t) 
   return true;
 }
 
-RTR_DEV bool hit_leaf(const DeviceScene &sc, int leaf, V3 o, V3 dir, V3 dn, HitRec &h) {
+template <class Geom>
+RTR_DEV bool hit_leaf(const Geom &g, int leaf, V3 o, V3 dir, V3 dn, HitRec &h) {
   int row = leaf & 0x3fffffff;
   h.leaf = leaf;
   if (leaf >> 30) {
     h.b1 = 0;
     h.b2 = 0;
-    return hit_sphere(sc, row, o, dn, h.t);
+    return hit_sphere(g, row, o, dn, h.t);
   }
-  return hit_triangle(sc, row, o, dir, dn, h.t, h.b1, h.b2);
+  return hit_triangle(g, row, o, dir, dn, h.t, h.b1, h.b2);
 }
 
 // Stack of the literal merge-tree evaluation below: one per wave, in LDS.  It is
@@ -126,7 +151,8 @@ struct MergeStack {
 
 // Literal evaluation of the reference's merge tree (src/BVH.cpp:66-80) with an
 // explicit stack; only used for rays on which a NaN hit distance was seen.
-RTR_DEV HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack &st) {
+template <class Geom>
+RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
   // frame: node index, phase (0 = enter, 1 = left done, 2 = right done), left result
   int sp = 0;
   st.node[0] = 0;
@@ -138,13 +164,13 @@ RTR_DEV HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack
     int i = st.node[sp];
     int ph = st.phase[sp];
     if (ph == 0) {
-      float4 lo = sc.nodes[2 * i], hi = sc.nodes[2 * i + 1];
+      float4 lo = g.node_lo(i), hi = g.node_hi(i);
       int leaf = (int)wbits(hi);
       ret.leaf = -1;
       if (!slab(lo, hi, o, dn)) { sp--; continue; }
       if (leaf >= 0) {
         HitRec h;
-        if (hit_leaf(sc, leaf, o, dir, dn, h)) ret = h;
+        if (hit_leaf(g, leaf, o, dir, dn, h)) ret = h;
         sp--;
         continue;
       }
@@ -156,7 +182,7 @@ RTR_DEV HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack
     } else if (ph == 1) {
       st.lt[sp] = ret.t; st.lb1[sp] = ret.b1; st.lb2[sp] = ret.b2; st.lleaf[sp] = ret.leaf;
       st.phase[sp] = 2;
-      st.node[sp + 1] = (int)wbits(sc.nodes[2 * (i + 1)]);  // right child = skip of the left child
+      st.node[sp + 1] = (int)wbits(g.node_lo(i + 1));  // right child = skip of the left child
       st.phase[sp + 1] = 0;
       sp++;
     } else {
@@ -171,22 +197,65 @@ RTR_DEV HitRec trace_tree(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack
   return ret;
 }
 
+// Certified filter in front of the exact slab test.
+//
+// The exact test divides six times per node, and an IEEE fp32 division is about
+// ten instructions on CDNA.  Only its boolean is needed, so the six quotients
+// are first estimated as a * RN(1/d).  For finite operands without under/overflow
+// the estimate q~ and the reference's RN(a/d) differ by at most 3 * 2^-24 * |q|
+// (reciprocal rounding, product rounding, quotient rounding).  x -> x +- c|x| is
+// monotonic, so the same relative bound carries through every min/max:
+//   tnear_exact in [tn - c|tn|, tn + c|tn|],  tfar_exact in [tf - c|tf|, tf + c|tf|].
+// Hence  tf - tn >= c(|tn|+|tf|)  proves the reference's `tnear <= tfar`, and
+// tn - tf > c(|tn|+|tf|) refutes it; anything in between is decided by the exact
+// test.  c = 2.5e-7 leaves room over 3 * 2^-24 = 1.79e-7 for the rounding of the
+// bound itself.  Returns 1 = hit, 0 = miss, 2 = undecided.
+//
+// Preconditions (checked once per ray / per scene, else the exact test is used):
+// direction components finite with magnitude >= 2^-40; origin components and box
+// planes either 0 or of magnitude in [2^-40, 2^40].  Then every a = plane - o is 0
+// or at least 2^-64 in magnitude and every quotient stays a normal number.
+RTR_DEV int slab_filter(float4 lo, float4 hi, V3 o, V3 inv) {
+  float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+  float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+  float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  float gap = tf - tn;
+  float thr = 2.5e-7f * (fabsf(tn) + fabsf(tf));
+  return gap >= thr ? 1 : (-gap > thr ? 0 : 2);
+}
+
+RTR_DEV bool filter_component_ok(float v) {
+  float a = fabsf(v);
+  return a == 0.0f || (a >= 9.094947017729282e-13f && a <= 1.099511627776e12f);  // 2^-40, 2^40
+}
+
 // Scene::intersect for one ray.
-RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeStack &wave_stack) {
+template <class Geom>
+RTR_DEV HitRec trace_closest(const Geom &g, int n_nodes, bool fast_planes, V3 o, V3 dir, V3 dn,
+                             MergeStack &wave_stack) {
   HitRec best;
   best.leaf = -1;
   best.t = 0; best.b1 = 0; best.b2 = 0;
   bool saw_nan = false;
   int i = 0;
-  const int n = sc.n_nodes;
+  const int n = n_nodes;
+  const bool fast = fast_planes && filter_component_ok(o.x) && filter_component_ok(o.y) &&
+                    filter_component_ok(o.z) && fabsf(dn.x) >= 9.094947017729282e-13f &&
+                    fabsf(dn.y) >= 9.094947017729282e-13f && fabsf(dn.z) >= 9.094947017729282e-13f &&
+                    fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
+  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
   while (i < n) {
-    float4 lo = sc.nodes[2 * i], hi = sc.nodes[2 * i + 1];
+    float4 lo = g.node_lo(i), hi = g.node_hi(i);
     int skip = (int)wbits(lo);
     int leaf = (int)wbits(hi);
-    if (slab(lo, hi, o, dn)) {
+    int decision = fast ? slab_filter(lo, hi, o, inv) : 2;
+    if (decision == 2) decision = slab(lo, hi, o, dn) ? 1 : 0;
+    if (decision) {
       if (leaf >= 0) {
         HitRec h;
-        if (hit_leaf(sc, leaf, o, dir, dn, h)) {
+        if (hit_leaf(g, leaf, o, dir, dn, h)) {
           saw_nan |= (h.t != h.t);
           bool keep = (best.leaf >= 0) && (best.t < h.t);
           if (!keep) best = h;
@@ -203,10 +272,27 @@ RTR_DEV HitRec trace_closest(const DeviceScene &sc, V3 o, V3 dir, V3 dn, MergeSt
   unsigned long long need = __ballot(saw_nan);
   while (need) {
     int l = __ffsll((long long)need) - 1;
-    if ((int)(threadIdx.x & 63u) == l) best = trace_tree(sc, o, dir, dn, wave_stack);
+    if ((int)(threadIdx.x & 63u) == l) best = trace_tree(g, o, dir, dn, wave_stack);
     need &= need - 1;
   }
   return best;
+}
+
+// Geometry staged in LDS by a whole workgroup (kernels call this before tracing,
+// every thread of the block, then __syncthreads()).
+constexpr int kLdsNodes = 192, kLdsTris = 96, kLdsSphs = 96;
+struct LdsScene {
+  float4 nodes[2 * kLdsNodes];
+  float4 tris[3 * kLdsTris];
+  float4 sphs[kLdsSphs];
+};
+RTR_DEV bool fits_lds(const DeviceScene &sc) {
+  return sc.n_nodes <= kLdsNodes && sc.n_tris <= kLdsTris && sc.n_sphs <= kLdsSphs;
+}
+RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthreads) {
+  for (int k = tid; k < 2 * sc.n_nodes; k += nthreads) s.nodes[k] = sc.nodes[k];
+  for (int k = tid; k < 3 * sc.n_tris; k += nthreads) s.tris[k] = sc.tris[k];
+  for (int k = tid; k < sc.n_sphs; k += nthreads) s.sphs[k] = sc.sphs[k];
 }
 
 // Intersection::postion / ::normal of a recorded hit (src/Trangle.cpp:23-24,
