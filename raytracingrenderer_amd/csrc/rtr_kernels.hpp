@@ -89,16 +89,17 @@ k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4
 }
 
 // ---- traversal over explicit ray arrays (the rtr_trace_closest entry point) ----
-// Closest hit from staged (LDS) or global geometry; kLds is chosen by the host
-// from the scene's size.
+// Closest hit for the 64 rays of a wave, from staged (LDS) or global geometry;
+// kLds is chosen by the host from the scene's size.  Every lane of the wave must
+// call this (valid = false where there is no ray).
 template <bool kLds>
-RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, V3 o, V3 d, V3 dn,
-                         MergeStack &stack) {
+RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, bool valid, V3 o, V3 d, V3 dn,
+                         WaveShared &ws) {
   if (kLds) {
     LdsGeom g{lds.nodes, lds.tris, lds.sphs};
-    return trace_closest(g, sc.n_nodes, sc.fast_planes != 0, o, d, dn, stack);
+    return trace_wave(g, sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
   }
-  return trace_closest(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, o, d, dn, stack);
+  return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
 }
 
 template <bool kLds>
@@ -106,18 +107,22 @@ __global__ void __launch_bounds__(kBlock)
 k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
             int32_t *__restrict__ prim, float *__restrict__ t, float *__restrict__ pos,
             float *__restrict__ nrm) {
-  __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ WaveShared wsh[kBlock / 64];
   __shared__ LdsScene lds;
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
     __syncthreads();
   }
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-  V3 d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  const bool valid = i < n;
+  V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+  if (valid) {
+    o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  }
   V3 dn = unit(d);
-  HitRec h = trace_any<kLds>(sc, lds, o, d, dn, stacks[threadIdx.x >> 6]);
+  HitRec h = trace_any<kLds>(sc, lds, valid, o, d, dn, wsh[threadIdx.x >> 6]);
+  if (!valid) return;
   prim[i] = hit_prim(sc, h);
   t[i] = h.t;
   V3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
@@ -131,17 +136,17 @@ template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir, int n,
                 float4 *__restrict__ hit) {
-  __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ WaveShared wsh[kBlock / 64];
   __shared__ LdsScene lds;
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
     __syncthreads();
   }
   int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  V3 d = xyz(dir[i]);
-  HitRec h = trace_any<kLds>(sc, lds, cam.eye, d, unit(d), stacks[threadIdx.x >> 6]);
-  hit[i] = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
+  const bool valid = i < n;
+  V3 d = valid ? xyz(dir[i]) : mk(1, 1, 1);
+  HitRec h = trace_any<kLds>(sc, lds, valid, cam.eye, d, unit(d), wsh[threadIdx.x >> 6]);
+  if (valid) hit[i] = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
 }
 
 // ---- traversal of the ray queue ----
@@ -149,7 +154,7 @@ template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
               const Counters *__restrict__ cnt, int parity) {
-  __shared__ MergeStack stacks[kBlock / 64];
+  __shared__ WaveShared wsh[kBlock / 64];
   __shared__ LdsScene lds;
   unsigned i = blockIdx.x * kBlock + threadIdx.x;
   const unsigned nq = cnt->qcount[parity];
@@ -159,13 +164,19 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
     stage_scene(sc, lds, threadIdx.x, kBlock);
     __syncthreads();
   }
-  if (i >= nq) return;
-  uint32_t e = queue[i];
-  uint32_t slot = e & 0x7fffffffu;
-  bool ext = e >> 31;
-  V3 o = xyz(p.A[slot]);
-  V3 d = xyz(ext ? p.K[slot] : p.J[slot]);
-  HitRec h = trace_any<kLds>(sc, lds, o, d, unit(d), stacks[threadIdx.x >> 6]);
+  const bool valid = i < nq;
+  uint32_t slot = 0;
+  bool ext = false;
+  V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+  if (valid) {
+    uint32_t e = queue[i];
+    slot = e & 0x7fffffffu;
+    ext = e >> 31;
+    o = xyz(p.A[slot]);
+    d = xyz(ext ? p.K[slot] : p.J[slot]);
+  }
+  HitRec h = trace_any<kLds>(sc, lds, valid, o, d, unit(d), wsh[threadIdx.x >> 6]);
+  if (!valid) return;
   float4 out = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
   if (ext) p.he[slot] = out; else p.hs[slot] = out;
 }

@@ -278,9 +278,154 @@ RTR_DEV HitRec trace_closest(const Geom &g, int n_nodes, bool fast_planes, V3 o,
   return best;
 }
 
+// ---------------------------------------------------------------------------
+// Wave-cooperative closest hit.
+//
+// Per-lane traversal leaves most lanes idle during primitive tests: at any
+// moment only the few lanes standing on a leaf need the (long) triangle or
+// sphere code, yet the whole wave steps through it.  Box tests never depend on
+// primitive results (the reference culls nothing by distance), so the two are
+// decoupled here:
+//   * each lane walks the tree doing box tests only; when it reaches a leaf whose
+//     box it hits, the pair (lane, node) is appended to a per-wave ring in LDS
+//     (one ring per primitive kind, positions from a 64-wide ballot);
+//   * as soon as a ring holds 64 pairs the whole wave tests them, one pair per
+//     lane, reading the ray of the pair's lane from LDS -- all 64 lanes busy with
+//     the same primitive kind; leftovers are drained at the end.
+// A test that hits publishes key = (orderable(t) << 32) | ~node with a 64-bit
+// LDS atomic min on its ray's slot.  The reference folds leaves left to right and
+// replaces the best hit unless it is strictly nearer (src/BVH.cpp:75-76); for
+// ordered distances that is "smallest t, and among equal t the LAST leaf in
+// depth-first order", which is exactly the minimum of these keys, in any order of
+// evaluation.  The pair that owns the minimum afterwards writes the full hit
+// record.  Rays that met a NaN distance take the literal merge-tree path.
+struct WaveShared {
+  union {
+    struct {
+      float4 ray0[64], ray1[64], ray2[64];  // {o, d.x} {d.y, d.z, dn.x, dn.y} {dn.z,-,-,-}
+      unsigned long long key[64];
+      float4 hit[64];  // {t, b1, b2, bits(leaf)}
+      uint32_t ring[2][128];
+    } w;
+    MergeStack merge;  // only used after everything above is dead
+  };
+  unsigned long long nan_mask;
+};
+
+RTR_DEV unsigned long long hit_key(float t, int node) {
+  uint32_t u = __float_as_uint(t + 0.0f);  // -0 -> +0: the reference compares them equal
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (uint32_t)(~node);
+}
+
+// One round: up to 64 pending (lane, node) pairs of one primitive kind.
+template <int kKind, class Geom>
+RTR_DEV void test_round(const Geom &g, WaveShared &ws, unsigned head, unsigned count) {
+  const unsigned lane = threadIdx.x & 63u;
+  if (lane < count) {
+    uint32_t e = ws.w.ring[kKind][(head + lane) & 127u];
+    unsigned r = e & 63u;
+    int node = (int)(e >> 6);
+    float4 a = ws.w.ray0[r], b = ws.w.ray1[r], c = ws.w.ray2[r];
+    V3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y), dn = mk(b.z, b.w, c.x);
+    int leaf = (int)wbits(g.node_hi(node));
+    int row = leaf & 0x3fffffff;
+    float t = 0, b1 = 0, b2 = 0;
+    bool hit = kKind ? hit_sphere(g, row, o, dn, t) : hit_triangle(g, row, o, d, dn, t, b1, b2);
+    if (hit) {
+      if (t != t) {
+        atomicOr(&ws.nan_mask, 1ull << r);
+      } else {
+        unsigned long long key = hit_key(t, node);
+        atomicMin(&ws.w.key[r], key);
+        // LDS executes a wave's operations in order: every lane's min is in place here
+        if (ws.w.key[r] == key) ws.w.hit[r] = make_float4(t, b1, b2, __int_as_float(leaf));
+      }
+    }
+  }
+}
+
+// Scene::intersect for the 64 rays of a wave.  Must be called by all 64 lanes
+// (valid = false for lanes without a ray).
+template <class Geom>
+RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool valid, V3 o, V3 dir,
+                          V3 dn, WaveShared &ws) {
+  const unsigned lane = threadIdx.x & 63u;
+  ws.w.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
+  ws.w.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
+  ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);
+  ws.w.key[lane] = ~0ull;
+  if (lane == 0) ws.nan_mask = 0;
+  const bool fast = fast_planes && filter_component_ok(o.x) && filter_component_ok(o.y) &&
+                    filter_component_ok(o.z) && fabsf(dn.x) >= 9.094947017729282e-13f &&
+                    fabsf(dn.y) >= 9.094947017729282e-13f && fabsf(dn.z) >= 9.094947017729282e-13f &&
+                    fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
+  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+  unsigned head[2] = {0, 0}, tail[2] = {0, 0};  // wave-uniform ring cursors
+  int i = 0;
+  for (;;) {
+    const bool alive = valid && i < n_nodes;
+    if (__ballot(alive) == 0) break;
+    bool cand = false;
+    int kind = 0, node = i;
+    if (alive) {
+      float4 lo = g.node_lo(i), hi = g.node_hi(i);
+      int skip = (int)wbits(lo);
+      int leaf = (int)wbits(hi);
+      int decision = fast ? slab_filter(lo, hi, o, inv) : 2;
+      if (decision == 2) decision = slab(lo, hi, o, dn) ? 1 : 0;
+      if (decision && leaf < 0) {
+        i = i + 1;
+      } else {
+        i = skip;  // missed box, or a leaf (whose subtree is itself)
+        cand = decision != 0;
+        kind = leaf >> 30;
+      }
+    }
+    unsigned long long m0 = __ballot(cand && kind == 0), m1 = __ballot(cand && kind != 0);
+    if (m0) {
+      if (cand && kind == 0)
+        ws.w.ring[0][(tail[0] + __popcll(m0 & ((1ull << lane) - 1ull))) & 127u] = lane | ((uint32_t)node << 6);
+      tail[0] += (unsigned)__popcll(m0);
+      if (tail[0] - head[0] >= 64u) {
+        test_round<0>(g, ws, head[0], 64u);
+        head[0] += 64u;
+      }
+    }
+    if (m1) {
+      if (cand && kind != 0)
+        ws.w.ring[1][(tail[1] + __popcll(m1 & ((1ull << lane) - 1ull))) & 127u] = lane | ((uint32_t)node << 6);
+      tail[1] += (unsigned)__popcll(m1);
+      if (tail[1] - head[1] >= 64u) {
+        test_round<1>(g, ws, head[1], 64u);
+        head[1] += 64u;
+      }
+    }
+  }
+  if (tail[0] != head[0]) test_round<0>(g, ws, head[0], tail[0] - head[0]);
+  if (tail[1] != head[1]) test_round<1>(g, ws, head[1], tail[1] - head[1]);
+
+  HitRec best;
+  best.leaf = -1;
+  best.t = 0; best.b1 = 0; best.b2 = 0;
+  if (ws.w.key[lane] != ~0ull) {
+    float4 h = ws.w.hit[lane];
+    best.t = h.x; best.b1 = h.y; best.b2 = h.z; best.leaf = __float_as_int(h.w);
+  }
+  // rare: a NaN distance was seen on some rays -> literal merge tree, one lane at a time
+  // (the merge stack overlays the rings, which are dead by now)
+  unsigned long long need = ws.nan_mask;
+  while (need) {
+    int l = __ffsll((long long)need) - 1;
+    if ((int)lane == l) best = trace_tree(g, o, dir, dn, ws.merge);
+    need &= need - 1;
+  }
+  return best;
+}
+
 // Geometry staged in LDS by a whole workgroup (kernels call this before tracing,
 // every thread of the block, then __syncthreads()).
-constexpr int kLdsNodes = 192, kLdsTris = 96, kLdsSphs = 96;
+constexpr int kLdsNodes = 64, kLdsTris = 48, kLdsSphs = 32;
 struct LdsScene {
   float4 nodes[2 * kLdsNodes];
   float4 tris[3 * kLdsTris];
