@@ -224,7 +224,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
 
   // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
   std::vector<float4> nodes;
-  bool fast_planes = true;  // precondition of the certified box filter (rtr_trace.hpp)
+  bool fast_planes = true;  // precondition of the division-free box test (rtr_trace.hpp)
   if (d->n_nodes > 0) {
     const int n = d->n_nodes;
     std::vector<int32_t> order;  // new index -> old index
@@ -274,7 +274,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
       hi.x = d->node_bmax[0][o]; hi.y = d->node_bmax[1][o]; hi.z = d->node_bmax[2][o];
       for (float v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) {
         float m = fabsf(v);
-        if (!(m == 0.0f || (m >= 9.094947017729282e-13f && m <= 1.099511627776e12f)))
+        if (!(m == 0.0f || (m >= kFastLo && m <= kFastHi)))
           fast_planes = false;
       }
       memcpy(&lo.w, &skip, 4);

@@ -97,7 +97,7 @@ RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, bool valid,
                          WaveShared &ws) {
   if (kLds) {
     LdsGeom g{lds.nodes, lds.tris, lds.sphs};
-    return trace_wave(g, sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
+    return trace_wave_scan(g, sc.nodes, sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
   }
   return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
 }

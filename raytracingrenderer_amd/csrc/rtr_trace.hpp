@@ -38,7 +38,7 @@ struct DeviceScene {
   const int32_t *prim_material;
   int32_t n_nodes;
   int32_t n_prims;
-  int32_t fast_planes;  // 1: every box plane is 0 or has magnitude in [2^-40, 2^40]
+  int32_t fast_planes;  // 1: every box plane is 0 or has magnitude in [2^-20, 2^20]
   int32_t n_tris, n_sphs;
 };
 
@@ -197,85 +197,50 @@ RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
   return ret;
 }
 
-// Certified filter in front of the exact slab test.
+// Bound3::intersect without IEEE division instructions, same boolean.
 //
-// The exact test divides six times per node, and an IEEE fp32 division is about
-// ten instructions on CDNA.  Only its boolean is needed, so the six quotients
-// are first estimated as a * RN(1/d).  For finite operands without under/overflow
-// the estimate q~ and the reference's RN(a/d) differ by at most 3 * 2^-24 * |q|
-// (reciprocal rounding, product rounding, quotient rounding).  x -> x +- c|x| is
-// monotonic, so the same relative bound carries through every min/max:
-//   tnear_exact in [tn - c|tn|, tn + c|tn|],  tfar_exact in [tf - c|tf|, tf + c|tf|].
-// Hence  tf - tn >= c(|tn|+|tf|)  proves the reference's `tnear <= tfar`, and
-// tn - tf > c(|tn|+|tf|) refutes it; anything in between is decided by the exact
-// test.  c = 2.5e-7 leaves room over 3 * 2^-24 = 1.79e-7 for the rounding of the
-// bound itself.  Returns 1 = hit, 0 = miss, 2 = undecided.
+// The reference divides six times per node and an IEEE fp32 division is about
+// ten instructions on CDNA.  With y = RN(1/d) formed once per ray and axis, each
+// quotient is rebuilt exactly by two residual corrections (Markstein):
+//   q0 = RN(a*y); r0 = fma(-d,q0,a); q1 = fma(r0,y,q0)   -> q1 within 1 ulp of a/d
+//   r1 = fma(-d,q1,a) (exact);       q2 = fma(r1,y,q1)   -> q2 = RN(a/d)
+// q2 is the correctly rounded quotient whenever y is the correctly rounded
+// reciprocal and nothing under- or overflows on the way, so min/max of the six
+// q2 and the final compare give the reference's result bit for bit.  The fma
+// calls are explicit; contraction stays off for everything else.
 //
-// Preconditions (checked once per ray / per scene, else the exact test is used):
-// direction components finite with magnitude >= 2^-40; origin components and box
-// planes either 0 or of magnitude in [2^-40, 2^40].  Then every a = plane - o is 0
-// or at least 2^-64 in magnitude and every quotient stays a normal number.
-RTR_DEV int slab_filter(float4 lo, float4 hi, V3 o, V3 inv) {
-  float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-  float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-  float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+// Preconditions (else the IEEE-division test above is used): direction
+// components finite with magnitude in [2^-20, 2]; origin components and box planes
+// 0 or of magnitude in [2^-20, 2^20].  Then every a = plane - o is 0 or at least
+// 2^-44, quotients lie in [2^-45, 2^41] and the residuals stay normal numbers.
+// All values are finite, so plain min/max equal the reference's swap-and-select.
+RTR_DEV float div_corrected(float a, float d, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-d, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-d, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
+RTR_DEV bool slab_fast(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
+  float ax = div_corrected(lo.x - o.x, d.x, y.x), bx = div_corrected(hi.x - o.x, d.x, y.x);
+  float ay = div_corrected(lo.y - o.y, d.y, y.y), by = div_corrected(hi.y - o.y, d.y, y.y);
+  float az = div_corrected(lo.z - o.z, d.z, y.z), bz = div_corrected(hi.z - o.z, d.z, y.z);
   float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
   float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-  float gap = tf - tn;
-  float thr = 2.5e-7f * (fabsf(tn) + fabsf(tf));
-  return gap >= thr ? 1 : (-gap > thr ? 0 : 2);
+  return tn <= tf;
 }
 
-RTR_DEV bool filter_component_ok(float v) {
+constexpr float kFastLo = 9.5367431640625e-07f;  // 2^-20
+constexpr float kFastHi = 1048576.0f;            // 2^20
+RTR_DEV bool fast_coordinate(float v) {
   float a = fabsf(v);
-  return a == 0.0f || (a >= 9.094947017729282e-13f && a <= 1.099511627776e12f);  // 2^-40, 2^40
+  return a == 0.0f || (a >= kFastLo && a <= kFastHi);
 }
-
-// Scene::intersect for one ray.
-template <class Geom>
-RTR_DEV HitRec trace_closest(const Geom &g, int n_nodes, bool fast_planes, V3 o, V3 dir, V3 dn,
-                             MergeStack &wave_stack) {
-  HitRec best;
-  best.leaf = -1;
-  best.t = 0; best.b1 = 0; best.b2 = 0;
-  bool saw_nan = false;
-  int i = 0;
-  const int n = n_nodes;
-  const bool fast = fast_planes && filter_component_ok(o.x) && filter_component_ok(o.y) &&
-                    filter_component_ok(o.z) && fabsf(dn.x) >= 9.094947017729282e-13f &&
-                    fabsf(dn.y) >= 9.094947017729282e-13f && fabsf(dn.z) >= 9.094947017729282e-13f &&
-                    fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
-  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
-  while (i < n) {
-    float4 lo = g.node_lo(i), hi = g.node_hi(i);
-    int skip = (int)wbits(lo);
-    int leaf = (int)wbits(hi);
-    int decision = fast ? slab_filter(lo, hi, o, inv) : 2;
-    if (decision == 2) decision = slab(lo, hi, o, dn) ? 1 : 0;
-    if (decision) {
-      if (leaf >= 0) {
-        HitRec h;
-        if (hit_leaf(g, leaf, o, dir, dn, h)) {
-          saw_nan |= (h.t != h.t);
-          bool keep = (best.leaf >= 0) && (best.t < h.t);
-          if (!keep) best = h;
-        }
-        i = skip;  // a leaf's subtree is itself
-      } else {
-        i = i + 1;
-      }
-    } else {
-      i = skip;
-    }
-  }
-  // rare: evaluate the merge tree literally, one lane of the wave at a time
-  unsigned long long need = __ballot(saw_nan);
-  while (need) {
-    int l = __ffsll((long long)need) - 1;
-    if ((int)(threadIdx.x & 63u) == l) best = trace_tree(g, o, dir, dn, wave_stack);
-    need &= need - 1;
-  }
-  return best;
+RTR_DEV bool fast_ray(V3 o, V3 dn) {
+  return fast_coordinate(o.x) && fast_coordinate(o.y) && fast_coordinate(o.z) &&
+         fabsf(dn.x) >= kFastLo && fabsf(dn.y) >= kFastLo && fabsf(dn.z) >= kFastLo &&
+         fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
 }
 
 // ---------------------------------------------------------------------------
@@ -356,10 +321,7 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
   ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);
   ws.w.key[lane] = ~0ull;
   if (lane == 0) ws.nan_mask = 0;
-  const bool fast = fast_planes && filter_component_ok(o.x) && filter_component_ok(o.y) &&
-                    filter_component_ok(o.z) && fabsf(dn.x) >= 9.094947017729282e-13f &&
-                    fabsf(dn.y) >= 9.094947017729282e-13f && fabsf(dn.z) >= 9.094947017729282e-13f &&
-                    fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
+  const bool fast = fast_planes && fast_ray(o, dn);
   const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
   unsigned head[2] = {0, 0}, tail[2] = {0, 0};  // wave-uniform ring cursors
   int i = 0;
@@ -372,13 +334,14 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
       float4 lo = g.node_lo(i), hi = g.node_hi(i);
       int skip = (int)wbits(lo);
       int leaf = (int)wbits(hi);
-      int decision = fast ? slab_filter(lo, hi, o, inv) : 2;
-      if (decision == 2) decision = slab(lo, hi, o, dn) ? 1 : 0;
-      if (decision && leaf < 0) {
+      bool pass;
+      if (fast) pass = slab_fast(lo, hi, o, dn, inv);
+      else pass = slab(lo, hi, o, dn);
+      if (pass && leaf < 0) {
         i = i + 1;
       } else {
         i = skip;  // missed box, or a leaf (whose subtree is itself)
-        cand = decision != 0;
+        cand = pass;
         kind = leaf >> 30;
       }
     }
@@ -414,6 +377,98 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
   }
   // rare: a NaN distance was seen on some rays -> literal merge tree, one lane at a time
   // (the merge stack overlays the rings, which are dead by now)
+  unsigned long long need = ws.nan_mask;
+  while (need) {
+    int l = __ffsll((long long)need) - 1;
+    if ((int)lane == l) best = trace_tree(g, o, dir, dn, ws.merge);
+    need &= need - 1;
+  }
+  return best;
+}
+
+// The same for scenes of at most 64 nodes: the wave scans the nodes together.
+//
+// In such a scene a ray's line crosses most boxes anyway (the reference's box
+// test has no t >= 0 clause; on the Cornell box a ray visits 23 of the 37 nodes
+// on average and the slowest lane of a wave 30), so per-lane walking buys little
+// and costs per-lane node loads, leaf/kind selects and divergent bookkeeping.
+// Here the node index k is wave-uniform: node data comes through the scalar
+// cache into SGPRs, the leaf branch is a scalar branch, and each lane only keeps
+// `resume`, the index at which it becomes active again (a lane that misses node k
+// sleeps until skip[k], i.e. through k's subtree -- exactly the nodes the
+// reference's recursion would not visit for that ray).  When no lane hits an
+// inner node the whole wave jumps to skip[k]: lanes already asleep there wake up
+// at or after skip[k], because they sleep since an ancestor of k.
+struct NodeRecord {  // one node as laid out in HBM (two float4)
+  float lox, loy, loz;
+  int skip;
+  float hix, hiy, hiz;
+  int leaf;
+};
+typedef const NodeRecord __attribute__((address_space(4))) const_node;
+
+template <class Geom>
+RTR_DEV HitRec trace_wave_scan(const Geom &g, const float4 *nodes_global, int n_nodes,
+                               bool fast_planes, bool valid, V3 o, V3 dir, V3 dn, WaveShared &ws) {
+  const unsigned lane = threadIdx.x & 63u;
+  ws.w.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
+  ws.w.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
+  ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);
+  ws.w.key[lane] = ~0ull;
+  if (lane == 0) ws.nan_mask = 0;
+  const bool fast = fast_planes && fast_ray(o, dn);
+  const bool any_slow = __ballot(valid && !fast) != 0;
+  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+  const const_node *nodes = (const const_node *)nodes_global;  // uniform index -> scalar loads
+  unsigned head0 = 0, tail0 = 0, head1 = 0, tail1 = 0;  // wave-uniform ring cursors
+  int resume = valid ? 0 : n_nodes;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int k = 0; k < n_nodes;) {
+    const float4 lo = make_float4(nodes[k].lox, nodes[k].loy, nodes[k].loz, 0.0f);
+    const float4 hi = make_float4(nodes[k].hix, nodes[k].hiy, nodes[k].hiz, 0.0f);
+    const int skip = nodes[k].skip;
+    const int leaf = nodes[k].leaf;
+    const bool active = k >= resume;
+    bool pass = slab_fast(lo, hi, o, dn, inv);
+    if (any_slow && !fast) pass = slab(lo, hi, o, dn);
+    pass = pass && active;
+    if (active && !pass) resume = skip;
+    const unsigned long long m = __ballot(pass);
+    if (leaf < 0) {
+      k = m ? k + 1 : skip;
+      continue;
+    }
+    if (m) {
+      const uint32_t entry = lane | ((uint32_t)k << 6);
+      const unsigned rank = (unsigned)__popcll(m & below), cnt = (unsigned)__popcll(m);
+      if (leaf >> 30) {
+        if (pass) ws.w.ring[1][(tail1 + rank) & 127u] = entry;
+        tail1 += cnt;
+        if (tail1 - head1 >= 64u) {
+          test_round<1>(g, ws, head1, 64u);
+          head1 += 64u;
+        }
+      } else {
+        if (pass) ws.w.ring[0][(tail0 + rank) & 127u] = entry;
+        tail0 += cnt;
+        if (tail0 - head0 >= 64u) {
+          test_round<0>(g, ws, head0, 64u);
+          head0 += 64u;
+        }
+      }
+    }
+    k = k + 1;
+  }
+  if (tail0 != head0) test_round<0>(g, ws, head0, tail0 - head0);
+  if (tail1 != head1) test_round<1>(g, ws, head1, tail1 - head1);
+
+  HitRec best;
+  best.leaf = -1;
+  best.t = 0; best.b1 = 0; best.b2 = 0;
+  if (ws.w.key[lane] != ~0ull) {
+    float4 h = ws.w.hit[lane];
+    best.t = h.x; best.b1 = h.y; best.b2 = h.z; best.leaf = __float_as_int(h.w);
+  }
   unsigned long long need = ws.nan_mask;
   while (need) {
     int l = __ffsll((long long)need) - 1;
