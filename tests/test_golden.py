@@ -200,3 +200,23 @@ def test_gpu_converged_image_matches_reference(gsc):
     rmse = float(np.sqrt(((rgb - ref) ** 2).mean()))
     assert rel < 0.005, rel
     assert rmse < 1.5 * noise, (rmse, noise)
+
+
+def test_division_free_quotient_is_exact(tmp_path):
+    """The traversal kernels rebuild a/d from RN(1/d) with two fma corrections instead of
+    dividing (rtr_trace.hpp: div_corrected).  oracle/check_division.c compares that sequence
+    with the IEEE quotient over the kernels' operand ranges; any mismatch fails."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_division")
+    flags = ["-O2", "-ffp-contract=off"]
+    try:
+        if " fma " in open("/proc/cpuinfo").read():
+            flags.append("-mfma")  # hardware fma: same results as glibc's fmaf, much faster
+    except OSError:
+        pass
+    subprocess.check_call(["gcc", *flags, "-o", exe, os.path.join(root, "oracle", "check_division.c"), "-lm"])
+    n = "20000000" if "-mfma" in flags else "1000000"
+    r = subprocess.run([exe, n, "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 mismatches" in r.stdout
