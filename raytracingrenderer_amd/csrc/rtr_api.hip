@@ -50,7 +50,7 @@ struct DevBuf {
 
 struct Workspace {
   DevBuf<float4> pix_dir, pix_hit, pc_pos, pc_nrm, pc_wi, partial;
-  DevBuf<float4> pool[13];
+  DevBuf<float4> pool[14];
   DevBuf<uint32_t> shade_list, queue;
   DevBuf<int32_t> cols;
   DevBuf<float> rgb;
@@ -614,7 +614,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   PixelCache pc{ws.pc_pos.ptr, ws.pc_nrm.ptr, ws.pc_wi.ptr};
   PathPool pp{ws.pool[0].ptr, ws.pool[1].ptr, ws.pool[2].ptr, ws.pool[3].ptr, ws.pool[4].ptr,
               ws.pool[5].ptr, ws.pool[6].ptr, ws.pool[7].ptr, ws.pool[8].ptr, ws.pool[9].ptr,
-              ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr};
+              ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr, ws.pool[13].ptr};
   Counters *cnt = ws.counters.ptr;
 
   // profile=1: every kernel is bracketed by a pair of events on the launch stream;
@@ -683,6 +683,8 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   HIP_TRY(hipStreamSynchronize(st));
   harvest();
   const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
+  a.n_shade = ws.host_counters->n_shade;
+  a.n_units = (uint32_t)n_units;
 
   uint64_t iters = 0;
   if (n_units > 0) {

@@ -44,8 +44,9 @@ struct PathPool {
   float4 *I;   // beta after the pending bounce, bits(global pixel id)
   float4 *J;   // shadow ray direction
   float4 *K;   // extension ray direction
-  float4 *hs;  // shadow hit  {t, b1, b2, bits(leaf)}
-  float4 *he;  // extension hit
+  float4 *hs;   // shadow hit: {hit point.xyz, distance}; point.x = NaN for a miss
+  float4 *he;   // extension hit: {hit point.xyz, bits(prim id or -1)}
+  float4 *he2;  // extension hit: {unit normal.xyz, -}
 };
 
 enum : uint32_t { kLive = 1u, kHasShadow = 2u, kHasExt = 4u, kHasUnit = 8u };
@@ -72,6 +73,7 @@ struct RenderArgs {
   int32_t max_depth;
   float rr;
   int32_t chunk_spp, n_chunks, pool;
+  uint32_t n_shade, n_units;  // known after k_classify
 };
 
 RTR_DEV unsigned lane_id() { return threadIdx.x & 63u; }
@@ -175,10 +177,20 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
     o = xyz(p.A[slot]);
     d = xyz(ext ? p.K[slot] : p.J[slot]);
   }
-  HitRec h = trace_any<kLds>(sc, lds, valid, o, d, unit(d), wsh[threadIdx.x >> 6]);
+  const V3 dn = unit(d);
+  HitRec h = trace_any<kLds>(sc, lds, valid, o, d, dn, wsh[threadIdx.x >> 6]);
   if (!valid) return;
-  float4 out = make_float4(h.t, h.b1, h.b2, __int_as_float(h.leaf));
-  if (ext) p.he[slot] = out; else p.hs[slot] = out;
+  // hand the path logic world-space results, so it needs neither the primitive
+  // nor the ray again: Intersection::postion / ::normal of src/Trangle.cpp:23-24,
+  // src/Sphere.cpp:25-26
+  V3 hp = mk(__int_as_float(0x7fc00000), 0, 0), hn = mk(0, 0, 0);
+  if (h.leaf >= 0) hit_point(sc, h, o, dn, hp, hn);
+  if (ext) {
+    p.he[slot] = pack(hp, (uint32_t)hit_prim(sc, h));
+    if (h.leaf >= 0) p.he2[slot] = pack(unit(hn), 0.0f);
+  } else {
+    p.hs[slot] = pack(hp, h.t);
+  }
 }
 
 // ---- first vertex of every pixel; pixels that need no sampling are finished here ----
@@ -268,40 +280,33 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
       beta = xyz(d4); k = wbits(d4);
       Lp = xyz(e4); k_end = wbits(e4);
       acc = xyz(f4); chunk = wbits(f4);
-      gpix = wbits(p.I[slot]);
     }
     if (flags & kLive) {
-      // next-event result: src/Render.cpp:95-107
+      // everything the two results need is fetched in one go: one memory round
+      // trip instead of one per dependent branch
+      const float4 hs4 = p.hs[slot], he4 = p.he[slot], he24 = p.he2[slot], g4 = p.G[slot],
+                   k4 = p.K[slot], i4 = p.I[slot];
+      gpix = wbits(i4);
+      // next-event result: src/Render.cpp:95-107.  A miss arrives as a NaN point,
+      // which fails the distance test like the reference's `testInter.hit` does.
       if (flags & kHasShadow) {
-        float4 hv = p.hs[slot];
-        HitRec h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
-        if (h.leaf >= 0) {
-          V3 hp, hn;
-          hit_point(sc, h, pos, unit(xyz(p.J[slot])), hp, hn);
-          float4 g4 = p.G[slot];
-          float dl = length(hp - xyz(h4));
-          if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
-            V3 term = xyz(g4) / (h.t * h.t) / g4.w;
-            Lp = Lp + beta * term;
-          }
+        float dl = length(xyz(hs4) - xyz(h4));
+        if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
+          V3 term = xyz(g4) / (hs4.w * hs4.w) / g4.w;
+          Lp = Lp + beta * term;
         }
       }
       // extension result: src/Render.cpp:117-125
       bool cont = false;
       if (flags & kHasExt) {
-        float4 hv = p.he[slot];
-        HitRec h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
-        if (h.leaf >= 0) {
-          int m2 = sc.prim_material[hit_prim(sc, h)];
+        int prim2 = (int)wbits(he4);
+        if (prim2 >= 0) {
+          int m2 = sc.prim_material[prim2];
           if (!mat_emissive(mats[m2]) && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
-            V3 w1 = xyz(p.K[slot]);
-            V3 dn = unit(w1);
-            V3 hp, hn;
-            hit_point(sc, h, pos, dn, hp, hn);
-            beta = xyz(p.I[slot]);
-            wi = -dn;
-            N = unit(hn);
-            pos = hp;
+            beta = xyz(i4);
+            wi = -unit(xyz(k4));
+            N = xyz(he24);
+            pos = xyz(he4);
             mat = (uint32_t)m2;
             depth++;
             cont = true;
@@ -323,7 +328,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     flags &= ~kHasUnit;
   }
   bool want_unit = in_range && !(flags & kHasUnit);
-  const unsigned n_units = cnt->n_shade * (unsigned)a.n_chunks;
+  const unsigned n_units = a.n_units;
   {
     unsigned long long m_fin = __ballot(unit_finished);
     unsigned long long m_want = __ballot(want_unit);
@@ -348,7 +353,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
       const unsigned base = s_base[0];
       unsigned u = base + before + (unsigned)__popcll(m_want & lanes_below());
       if (base < n_units && u < n_units) {
-        unsigned ns = cnt->n_shade;
+        unsigned ns = a.n_shade;
         chunk = u / ns;
         lp = shade_list[u - chunk * ns];
         k = chunk * (uint32_t)a.chunk_spp;
