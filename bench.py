@@ -190,6 +190,7 @@ def main():
                        "parallelism": "columns, %d-col interleaved tiles x %d gpu, 1 gather" % (tile, world)},
             "mrays_per_s_unique": rays_total / elapsed / 1e6,
             "mrays_per_s_reference_equivalent": 5.29 * samples / elapsed / 1e6,
+            "iterations_per_step_rank0": agg["iterations"] / args.steps,
             "rays_per_sample": rays_total / samples,
             "vertices_per_sample": vert_total / samples,
             "kernel_ms_per_step_rank0": {"trace": agg["ms_trace"] / args.steps,

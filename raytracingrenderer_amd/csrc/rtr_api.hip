@@ -55,14 +55,21 @@ struct Workspace {
   DevBuf<int32_t> cols;
   DevBuf<float> rgb;
   DevBuf<Counters> counters;
-  Counters *host_counters = nullptr;  // pinned
+  DevBuf<BlockCounters> block_counters;
+  Counters *host_counters = nullptr;             // pinned
+  BlockCounters *host_block_counters = nullptr;  // pinned
+  size_t host_block_cap = 0;
   void release() {
     pix_dir.release(); pix_hit.release(); pc_pos.release(); pc_nrm.release(); pc_wi.release();
     partial.release();
     for (auto &b : pool) b.release();
     shade_list.release(); queue.release(); cols.release(); rgb.release(); counters.release();
+    block_counters.release();
     if (host_counters) (void)hipHostFree(host_counters);
+    if (host_block_counters) (void)hipHostFree(host_block_counters);
     host_counters = nullptr;
+    host_block_counters = nullptr;
+    host_block_cap = 0;
   }
 };
 
@@ -591,11 +598,13 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (a.n_pix == 0) return RTR_OK;
   size_t max_units = (size_t)a.n_pix * a.n_chunks;
   if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
-  size_t pool = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
+  // upper bound of the pool; the exact size follows from the number of pixels
+  // that need sampling (known after k_classify)
+  size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
+  size_t pool = pool_target + (size_t)a.n_pix;  // lanes*per_pixel never exceeds this
   if (pool > max_units) pool = max_units;
   pool = (pool + kLogicBlock - 1) / kLogicBlock * kLogicBlock;
   if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
-  a.pool = (int)pool;
   CameraSetup cs = camera_setup(*cam, a.H);
 
   HIP_TRY(ws.cols.reserve(cols.size()));
@@ -607,15 +616,25 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   HIP_TRY(ws.shade_list.reserve(a.n_pix));
   HIP_TRY(ws.partial.reserve(max_units));
   for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
-  HIP_TRY(ws.queue.reserve(2 * pool));
+  HIP_TRY(ws.queue.reserve(2 * pool));  // one segment of kSegment entries per k_logic workgroup
   HIP_TRY(ws.counters.reserve(1));
   if (!ws.host_counters) HIP_TRY(hipHostMalloc((void **)&ws.host_counters, sizeof(Counters)));
+  size_t n_blocks = pool / kLogicBlock;  // capacity; the launch uses what the schedule needs
+  HIP_TRY(ws.block_counters.reserve(n_blocks));
+  if (ws.host_block_cap < n_blocks) {
+    if (ws.host_block_counters) (void)hipHostFree(ws.host_block_counters);
+    ws.host_block_counters = nullptr;
+    ws.host_block_cap = 0;
+    HIP_TRY(hipHostMalloc((void **)&ws.host_block_counters, n_blocks * sizeof(BlockCounters)));
+    ws.host_block_cap = n_blocks;
+  }
 
   PixelCache pc{ws.pc_pos.ptr, ws.pc_nrm.ptr, ws.pc_wi.ptr};
   PathPool pp{ws.pool[0].ptr, ws.pool[1].ptr, ws.pool[2].ptr, ws.pool[3].ptr, ws.pool[4].ptr,
               ws.pool[5].ptr, ws.pool[6].ptr, ws.pool[7].ptr, ws.pool[8].ptr, ws.pool[9].ptr,
               ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr, ws.pool[13].ptr};
   Counters *cnt = ws.counters.ptr;
+  BlockCounters *bc = ws.block_counters.ptr;
 
   // profile=1: every kernel is bracketed by a pair of events on the launch stream;
   // elapsed times are read back only after a synchronisation the render needs
@@ -659,7 +678,6 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
 
   HIP_TRY(hipMemcpyAsync(ws.cols.ptr, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), st));
-  HIP_TRY(hipMemsetAsync(ws.pool[7].ptr, 0, pool * sizeof(float4), st));  // flags = 0: no unit
   uint64_t trace_launches = 0;
   HIP_TRY(timed(kOther, [&] {
     hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, cs,
@@ -685,33 +703,60 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
   a.n_shade = ws.host_counters->n_shade;
   a.n_units = (uint32_t)n_units;
+  if (n_units > 0) {
+    // static unit schedule (see k_logic): `lanes` pixel-list entries in flight,
+    // `per_pixel` slots sharing the chunks of one entry
+    size_t lanes = a.n_shade < pool_target ? a.n_shade : pool_target;
+    size_t per_pixel = (pool_target + lanes / 2) / lanes;
+    if (per_pixel < 1) per_pixel = 1;
+    if (per_pixel > (size_t)a.n_chunks) per_pixel = a.n_chunks;
+    a.unit_lanes = (uint32_t)lanes;
+    a.unit_per_pixel = (uint32_t)per_pixel;
+    size_t used = lanes * per_pixel;
+    used = (used + kLogicBlock - 1) / kLogicBlock * kLogicBlock;
+    if (used > pool) return fail(RTR_ERR_DEVICE, "internal: pool smaller than the unit schedule");
+    pool = used;
+    n_blocks = pool / kLogicBlock;
+  }
+  a.pool = (int)pool;
 
-  uint64_t iters = 0;
+  uint64_t iters = 0, total_rays = 0, total_vertices = 0;
   if (n_units > 0) {
     const int batch = 16;
+    const unsigned logic_grid = (unsigned)n_blocks;
+    const unsigned trace_grid = (unsigned)(n_blocks * (kSegment / kBlock));
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
+        a.first = iters == 0 ? 1 : 0;
         HIP_TRY(timed(kLogic, [&] {
-          hipLaunchKernelGGL(k_logic, dim3((unsigned)((pool + kLogicBlock - 1) / kLogicBlock)), dim3(kLogicBlock), 0, st, a, s->ds, s->dl,
-                             s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, cnt,
+          hipLaunchKernelGGL(k_logic, dim3(logic_grid), dim3(kLogicBlock), 0, st, a, s->ds, s->dl,
+                             s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
                              ws.partial.ptr, parity);
         }));
         HIP_TRY(timed(kTrace, [&] {
           if (s->lds_geometry)
-            hipLaunchKernelGGL(k_trace_queue<true>, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st,
-                               s->ds, pp, ws.queue.ptr, cnt, parity);
+            hipLaunchKernelGGL(k_trace_queue<true>, dim3(trace_grid), dim3(kBlock), 0, st, s->ds, pp,
+                               ws.queue.ptr, bc, parity);
           else
-            hipLaunchKernelGGL(k_trace_queue<false>, dim3(blocks_for(2 * pool)), dim3(kBlock), 0, st,
-                               s->ds, pp, ws.queue.ptr, cnt, parity);
+            hipLaunchKernelGGL(k_trace_queue<false>, dim3(trace_grid), dim3(kBlock), 0, st, s->ds, pp,
+                               ws.queue.ptr, bc, parity);
         }));
         trace_launches++;
         iters++;
       }
-      HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ws.host_block_counters, bc, n_blocks * sizeof(BlockCounters),
+                             hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       harvest();
-      if (ws.host_counters->units_done >= n_units) break;
+      uint64_t done = 0;
+      total_rays = total_vertices = 0;
+      for (size_t k = 0; k < n_blocks; k++) {
+        done += ws.host_block_counters[k].done;
+        total_rays += ws.host_block_counters[k].rays;
+        total_vertices += ws.host_block_counters[k].vertices;
+      }
+      if (done >= n_units) break;
       if (iters > (uint64_t)1 << 40) return fail(RTR_ERR_DEVICE, "render did not terminate");
     }
   }
@@ -727,8 +772,8 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   }
   if (stats) {
     stats->samples = (uint64_t)a.n_pix * a.spp;
-    stats->rays = ws.host_counters->rays + (uint64_t)a.n_pix;  // queue rays + primary rays
-    stats->vertices = ws.host_counters->vertices;
+    stats->rays = total_rays + (uint64_t)a.n_pix;  // queue rays + primary rays
+    stats->vertices = total_vertices;
     stats->iterations = iters;
     stats->chunk_spp = a.chunk_spp;
     stats->pool_size = a.pool;

@@ -19,8 +19,9 @@
 namespace rtr {
 
 constexpr int kBlock = 256;
-constexpr int kLogicBlock = 1024;  // 16 waves share one set of global atomics
+constexpr int kLogicBlock = 1024;
 constexpr int kLogicWaves = kLogicBlock / 64;
+constexpr int kSegment = 2 * kLogicBlock;  // queue entries owned by one k_logic workgroup
 
 struct CameraSetup {  // src/Render.cpp:639-649, computed on the host
   V3 eye, front, hstep, vstep;
@@ -51,20 +52,21 @@ struct PathPool {
 
 enum : uint32_t { kLive = 1u, kHasShadow = 2u, kHasExt = 4u, kHasUnit = 8u };
 
-// Each hot counter sits on its own 128-byte line: they are hit by returning
-// atomics from every workgroup, and sharing a line would serialise them.
-struct alignas(128) Counters {
-  unsigned int qcount[2];  // rays queued by iteration parity
-  unsigned int n_shade;    // pixels that need sampling
-  unsigned int pad0[29];
-  unsigned int next_unit;  // work-unit dispenser
-  unsigned int pad1[31];
-  unsigned int units_done;
-  unsigned int pad2[31];
-  unsigned long long vertices;
-  unsigned long long pad3[15];
-  unsigned long long rays;  // written by one thread per traversal launch
-  unsigned long long pad4[15];
+struct Counters {
+  unsigned int n_shade;  // pixels that need sampling (k_classify)
+  unsigned int pad[3];
+};
+
+// The render loop uses no global atomics.  Every k_logic workgroup owns one
+// record and one fixed segment of the ray queue; the host adds the records up.
+// (Per-wave, and then per-workgroup, atomics on shared counters used to be the
+// largest single cost of the path-logic kernel.)
+struct BlockCounters {
+  unsigned int qcount[2];       // rays this workgroup queued, by iteration parity
+  unsigned int done;            // work units finished so far
+  unsigned int pad;
+  unsigned long long vertices;  // path vertices shaded so far
+  unsigned long long rays;      // rays traced so far (written by the traversal kernel)
 };
 
 struct RenderArgs {
@@ -74,6 +76,8 @@ struct RenderArgs {
   float rr;
   int32_t chunk_spp, n_chunks, pool;
   uint32_t n_shade, n_units;  // known after k_classify
+  int32_t first;              // 1 on the first iteration: no slot has a unit yet
+  uint32_t unit_lanes, unit_per_pixel;  // static unit schedule, see k_logic
 };
 
 RTR_DEV unsigned lane_id() { return threadIdx.x & 63u; }
@@ -155,23 +159,31 @@ k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir,
 template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
-              const Counters *__restrict__ cnt, int parity) {
+              BlockCounters *__restrict__ bc, int parity) {
   __shared__ WaveShared wsh[kBlock / 64];
   __shared__ LdsScene lds;
-  unsigned i = blockIdx.x * kBlock + threadIdx.x;
-  const unsigned nq = cnt->qcount[parity];
-  if (i == 0) const_cast<Counters *>(cnt)->rays += nq;  // the only writer of this word
-  if (blockIdx.x * kBlock >= nq) return;  // whole workgroup has nothing to do
+  // workgroup -> (queue segment, part of it); a segment holds the rays of one
+  // k_logic workgroup, packed from its start.
+  // Workgroups are dealt to the 8 XCDs round-robin.  Numbering (segment, part) with
+  // the segment fastest puts equally many full, partial and empty parts on every
+  // XCD; with the part fastest, all the empty last parts landed on one XCD and the
+  // partly filled ones on another, idling a quarter of the chip.
+  const unsigned n_seg = gridDim.x / (kSegment / kBlock);
+  const unsigned seg = blockIdx.x % n_seg;
+  const unsigned off = (blockIdx.x / n_seg) * kBlock;
+  const unsigned nq = bc[seg].qcount[parity];
+  if (off >= nq) return;  // whole workgroup has nothing to do
+  if (off == 0 && threadIdx.x == 0) bc[seg].rays += nq;  // the only writer of this word
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
     __syncthreads();
   }
-  const bool valid = i < nq;
+  const bool valid = off + threadIdx.x < nq;
   uint32_t slot = 0;
   bool ext = false;
   V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
   if (valid) {
-    uint32_t e = queue[i];
+    uint32_t e = queue[(size_t)seg * kSegment + off + threadIdx.x];
     slot = e & 0x7fffffffu;
     ext = e >> 31;
     o = xyz(p.A[slot]);
@@ -252,34 +264,28 @@ k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats
 __global__ void __launch_bounds__(kLogicBlock)
 k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
         PixelCache pc, PathPool p, const uint32_t *__restrict__ shade_list,
-        uint32_t *__restrict__ queue, Counters *__restrict__ cnt, float4 *__restrict__ partial,
+        uint32_t *__restrict__ queue, BlockCounters *__restrict__ bc, float4 *__restrict__ partial,
         int parity) {
-  // Counts are first combined across the workgroup's 16 waves in LDS so that a
-  // workgroup issues one returning atomic per counter instead of one per wave:
-  // with a million slots, per-wave atomics on a handful of words were the
-  // kernel's whole run time.
-  __shared__ unsigned s_count[5][kLogicWaves];
-  __shared__ unsigned s_base[2];
+  __shared__ unsigned s_count[4][kLogicWaves];
   const int slot = blockIdx.x * kLogicBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
   const bool in_range = slot < a.pool;
-  if (slot == 0) cnt->qcount[parity ^ 1] = 0;
 
   uint32_t flags = 0;
   V3 pos = mk(0, 0, 0), N = pos, wi = pos, beta = pos, Lp = pos, acc = pos;
-  uint32_t mat = 0, depth = 0, lp = 0, k = 0, k_end = 0, chunk = 0, gpix = 0;
-  if (in_range) {
+  uint32_t mat = 0, depth = 0, lp = 0, k = 0, k_end = 0, unit_id = 0xffffffffu, gpix = 0;
+  if (in_range && !a.first) {
     float4 h4 = p.Hh[slot];
+    float4 f4 = p.F[slot];
     flags = wbits(h4);
+    acc = xyz(f4); unit_id = wbits(f4);
     if (flags & kHasUnit) {
-      float4 a4 = p.A[slot], b4 = p.B[slot], c4 = p.C[slot], d4 = p.D[slot], e4 = p.E[slot],
-             f4 = p.F[slot];
+      float4 a4 = p.A[slot], b4 = p.B[slot], c4 = p.C[slot], d4 = p.D[slot], e4 = p.E[slot];
       pos = xyz(a4); mat = wbits(a4);
       N = xyz(b4); depth = wbits(b4);
       wi = xyz(c4); lp = wbits(c4);
       beta = xyz(d4); k = wbits(d4);
       Lp = xyz(e4); k_end = wbits(e4);
-      acc = xyz(f4); chunk = wbits(f4);
     }
     if (flags & kLive) {
       // everything the two results need is fetched in one go: one memory round
@@ -321,47 +327,45 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     }
   }
 
-  // a slot without a live path starts the next sample of its unit, or a new unit
+  // A slot without a live path starts the next sample of its unit, or its next
+  // unit.  Units are dealt statically and pixel-affine: the pool is `lanes` slot
+  // lanes times `per_pixel` slots; slot s serves pixel-list entries s % lanes,
+  // + lanes, + 2*lanes, ... and, within an entry, chunks s / lanes, + per_pixel, ...
+  // Neighbouring lanes of a wave therefore always restart at neighbouring pixels
+  // (coherent first vertices and shadow rays), every slot gets the same number of
+  // units, and no dispenser or atomic is involved.  unit_id = entry * n_chunks + chunk.
+  const unsigned lanes = a.unit_lanes, per_pixel = a.unit_per_pixel, nch = (unsigned)a.n_chunks;
   bool unit_finished = in_range && (flags & kHasUnit) && !(flags & kLive) && k >= k_end;
+  bool unit_changed = false;
   if (unit_finished) {
+    unsigned chunk = unit_id % nch;
     partial[(size_t)chunk * a.n_pix + lp] = pack(acc, 0.0f);
     flags &= ~kHasUnit;
   }
-  bool want_unit = in_range && !(flags & kHasUnit);
-  const unsigned n_units = a.n_units;
-  {
-    unsigned long long m_fin = __ballot(unit_finished);
-    unsigned long long m_want = __ballot(want_unit);
-    if (lane_id() == 0) {
-      s_count[0][wave] = (unsigned)__popcll(m_fin);
-      s_count[1][wave] = (unsigned)__popcll(m_want);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned fin = 0, want = 0;
-      for (int w = 0; w < kLogicWaves; w++) { fin += s_count[0][w]; want += s_count[1][w]; }
-      if (fin) atomicAdd(&cnt->units_done, fin);
-      unsigned base = n_units;
-      if (want && *(volatile unsigned *)&cnt->next_unit < n_units)
-        base = atomicAdd(&cnt->next_unit, want);
-      s_base[0] = base;
-    }
-    __syncthreads();
-    if (want_unit) {
-      unsigned before = 0;
-      for (int w = 0; w < wave; w++) before += s_count[1][w];
-      const unsigned base = s_base[0];
-      unsigned u = base + before + (unsigned)__popcll(m_want & lanes_below());
-      if (base < n_units && u < n_units) {
-        unsigned ns = a.n_shade;
-        chunk = u / ns;
-        lp = shade_list[u - chunk * ns];
-        k = chunk * (uint32_t)a.chunk_spp;
-        k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
-        acc = mk(0, 0, 0);
-        gpix = wbits(pc.wi[lp]);
-        flags |= kHasUnit;
+  if (in_range && !(flags & kHasUnit) && (a.first || unit_id != 0xffffffffu)) {
+    unsigned entry, chunk;
+    if (a.first) {
+      entry = (unsigned)slot % lanes;
+      chunk = (unsigned)slot / lanes;
+    } else {
+      entry = unit_id / nch;
+      chunk = unit_id - entry * nch + per_pixel;
+      if (chunk >= nch) {
+        chunk = (unsigned)slot / lanes;
+        entry += lanes;
       }
+    }
+    unit_changed = true;
+    if (entry < a.n_shade && chunk < nch) {
+      unit_id = entry * nch + chunk;
+      lp = shade_list[entry];
+      k = chunk * (uint32_t)a.chunk_spp;
+      k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+      acc = mk(0, 0, 0);
+      gpix = wbits(pc.wi[lp]);
+      flags |= kHasUnit;
+    } else {
+      unit_id = 0xffffffffu;  // this slot has no more work
     }
   }
   bool live = in_range && (flags & kHasUnit);
@@ -375,6 +379,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     Lp = mk(0, 0, 0);
     depth = 0;
     flags |= kLive;
+    unit_changed = true;  // acc moved on
   }
 
   // shade the current vertex: src/Render.cpp:90-116
@@ -419,44 +424,44 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     p.C[slot] = pack(wi, lp);
     p.D[slot] = pack(beta, k);
     p.E[slot] = pack(Lp, k_end);
-    p.F[slot] = pack(acc, chunk);
+    if (unit_changed) p.F[slot] = pack(acc, unit_id);
     p.Hh[slot] = pack(ls.pos, flags);
-  } else if (in_range) {
+  } else if (in_range && (unit_changed || a.first)) {
+    p.F[slot] = pack(acc, unit_id);
     p.Hh[slot] = pack(mk(0, 0, 0), 0u);
   }
 
-  // compaction of the emitted rays into the queue: 64-wide ballots give each
-  // lane its rank inside the wave, LDS combines the waves, one atomic per
-  // workgroup reserves the range.  A workgroup's shadow rays come first, then
-  // its extension rays, so traversal waves are mostly of one kind.
-  unsigned long long ms = __ballot(has_shadow), me = __ballot(has_ext), ml = __ballot(live);
+  // Compaction of the emitted rays into this workgroup's queue segment: 64-wide
+  // ballots give each lane its rank inside the wave, LDS combines the waves.  The
+  // workgroup's shadow rays come first, then its extension rays, so traversal
+  // waves are mostly of one kind.
+  unsigned long long ms = __ballot(has_shadow), me = __ballot(has_ext), ml = __ballot(live),
+                     mf = __ballot(unit_finished);
   if (lane_id() == 0) {
-    s_count[2][wave] = (unsigned)__popcll(ms);
-    s_count[3][wave] = (unsigned)__popcll(me);
-    s_count[4][wave] = (unsigned)__popcll(ml);
+    s_count[0][wave] = (unsigned)__popcll(ms);
+    s_count[1][wave] = (unsigned)__popcll(me);
+    s_count[2][wave] = (unsigned)__popcll(ml);
+    s_count[3][wave] = (unsigned)__popcll(mf);
   }
   __syncthreads();
+  unsigned sh_before = 0, ext_before = 0, sh_total = 0, ext_total = 0;
+  for (int w = 0; w < kLogicWaves; w++) {
+    unsigned cs = s_count[0][w], ce = s_count[1][w];
+    if (w < wave) { sh_before += cs; ext_before += ce; }
+    sh_total += cs;
+    ext_total += ce;
+  }
   if (threadIdx.x == 0) {
-    unsigned ns = 0, ne = 0, nl = 0;
-    for (int w = 0; w < kLogicWaves; w++) { ns += s_count[2][w]; ne += s_count[3][w]; nl += s_count[4][w]; }
-    unsigned base = 0;
-    if (ns + ne) base = atomicAdd(&cnt->qcount[parity], ns + ne);
-    if (nl) atomicAdd(&cnt->vertices, (unsigned long long)nl);
-    s_base[1] = base;
+    unsigned nl = 0, nf = 0;
+    for (int w = 0; w < kLogicWaves; w++) { nl += s_count[2][w]; nf += s_count[3][w]; }
+    BlockCounters &b = bc[blockIdx.x];
+    b.qcount[parity] = sh_total + ext_total;
+    if (a.first) { b.done = nf; b.vertices = nl; b.rays = 0; b.qcount[parity ^ 1] = 0; }
+    else { b.done += nf; b.vertices += nl; }
   }
-  __syncthreads();
-  if (has_shadow || has_ext) {
-    unsigned sh_before = 0, ext_before = 0, sh_total = 0;
-    for (int w = 0; w < kLogicWaves; w++) {
-      unsigned cs = s_count[2][w];
-      if (w < wave) { sh_before += cs; ext_before += s_count[3][w]; }
-      sh_total += cs;
-    }
-    const unsigned base = s_base[1];
-    if (has_shadow) queue[base + sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
-    if (has_ext)
-      queue[base + sh_total + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
-  }
+  uint32_t *seg = queue + (size_t)blockIdx.x * kSegment;
+  if (has_shadow) seg[sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
+  if (has_ext) seg[sh_total + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
 }
 
 // ---- color / spp: src/Render.cpp:661-662 ----

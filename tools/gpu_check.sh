@@ -9,5 +9,5 @@ timeout -k 10 300 python -u bench.py --steps 2 --warmup 1 --no-cpu-baseline > gp
 python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/bench_dev.log").read().strip().splitlines()[-1])
-print("Msamples/s %.1f  ms/step %.1f  kernels %s  trace avg ms %.4f  frac %.4f" % (d["value"], d["ms_per_step"], {k: round(v,1) for k,v in d["kernel_ms_per_step_rank0"].items()}, d["roofline"]["avg_launch_ms"], d["roofline"]["frac"]))
+print("Msamples/s %.1f  ms/step %.1f iters %d kernels %s  trace avg ms %.4f  frac %.4f" % (d["value"], d["ms_per_step"], d["iterations_per_step_rank0"], {k: round(v,1) for k,v in d["kernel_ms_per_step_rank0"].items()}, d["roofline"]["avg_launch_ms"], d["roofline"]["frac"]))
 PY
