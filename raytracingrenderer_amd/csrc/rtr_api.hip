@@ -603,7 +603,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
   size_t pool = pool_target + (size_t)a.n_pix;  // lanes*per_pixel never exceeds this
   if (pool > max_units) pool = max_units;
-  pool = (pool + kLogicBlock - 1) / kLogicBlock * kLogicBlock;
+  pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
   if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
   CameraSetup cs = camera_setup(*cam, a.H);
 
@@ -713,7 +713,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     a.unit_lanes = (uint32_t)lanes;
     a.unit_per_pixel = (uint32_t)per_pixel;
     size_t used = lanes * per_pixel;
-    used = (used + kLogicBlock - 1) / kLogicBlock * kLogicBlock;
+    used = (used + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
     if (used > pool) return fail(RTR_ERR_DEVICE, "internal: pool smaller than the unit schedule");
     pool = used;
     n_blocks = pool / kLogicBlock;
@@ -724,7 +724,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (n_units > 0) {
     const int batch = 16;
     const unsigned logic_grid = (unsigned)n_blocks;
-    const unsigned trace_grid = (unsigned)(n_blocks * (kSegment / kBlock));
+    const unsigned trace_grid = (unsigned)(n_blocks / kGroup * kGroupParts);
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
@@ -753,7 +753,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       total_rays = total_vertices = 0;
       for (size_t k = 0; k < n_blocks; k++) {
         done += ws.host_block_counters[k].done;
-        total_rays += ws.host_block_counters[k].rays;
+        total_rays += ws.host_block_counters[k].rays[0] + ws.host_block_counters[k].rays[1];
         total_vertices += ws.host_block_counters[k].vertices;
       }
       if (done >= n_units) break;

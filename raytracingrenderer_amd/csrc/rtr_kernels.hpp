@@ -19,9 +19,15 @@
 namespace rtr {
 
 constexpr int kBlock = 256;
-constexpr int kLogicBlock = 1024;
+constexpr int kLogicBlock = 256;
 constexpr int kLogicWaves = kLogicBlock / 64;
 constexpr int kSegment = 2 * kLogicBlock;  // queue entries owned by one k_logic workgroup
+// The traversal kernel reads kGroup consecutive segments as one packed stream, so only the
+// last wave per GROUP is partly filled; the path-logic workgroups can then be small (better
+// latency hiding, several per CU) without leaving half a wave idle per workgroup.
+constexpr int kGroup = 4;
+constexpr int kStreamParts = kGroup * kLogicBlock / kBlock;  // traversal workgroups per stream
+constexpr int kGroupParts = 2 * kStreamParts;  // a group has a shadow stream and an extension stream
 
 struct CameraSetup {  // src/Render.cpp:639-649, computed on the host
   V3 eye, front, hstep, vstep;
@@ -62,11 +68,11 @@ struct Counters {
 // (Per-wave, and then per-workgroup, atomics on shared counters used to be the
 // largest single cost of the path-logic kernel.)
 struct BlockCounters {
-  unsigned int qcount[2];       // rays this workgroup queued, by iteration parity
+  unsigned int qcount[2][2];    // rays this workgroup queued: [iteration parity][0 shadow, 1 extension]
   unsigned int done;            // work units finished so far
   unsigned int pad;
   unsigned long long vertices;  // path vertices shaded so far
-  unsigned long long rays;      // rays traced so far (written by the traversal kernel)
+  unsigned long long rays[2];   // rays traced so far, per stream (written by the traversal kernel)
 };
 
 struct RenderArgs {
@@ -162,28 +168,43 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
               BlockCounters *__restrict__ bc, int parity) {
   __shared__ WaveShared wsh[kBlock / 64];
   __shared__ LdsScene lds;
-  // workgroup -> (queue segment, part of it); a segment holds the rays of one
-  // k_logic workgroup, packed from its start.
-  // Workgroups are dealt to the 8 XCDs round-robin.  Numbering (segment, part) with
-  // the segment fastest puts equally many full, partial and empty parts on every
+  // workgroup -> (group of kGroup queue segments, part of their concatenation).
+  // Workgroups are dealt to the 8 XCDs round-robin.  Numbering (group, part) with
+  // the group fastest puts equally many full, partial and empty parts on every
   // XCD; with the part fastest, all the empty last parts landed on one XCD and the
   // partly filled ones on another, idling a quarter of the chip.
-  const unsigned n_seg = gridDim.x / (kSegment / kBlock);
-  const unsigned seg = blockIdx.x % n_seg;
-  const unsigned off = (blockIdx.x / n_seg) * kBlock;
-  const unsigned nq = bc[seg].qcount[parity];
-  if (off >= nq) return;  // whole workgroup has nothing to do
-  if (off == 0 && threadIdx.x == 0) bc[seg].rays += nq;  // the only writer of this word
+  const unsigned n_grp = gridDim.x / kGroupParts;
+  const unsigned grp = blockIdx.x % n_grp;
+  const unsigned gpart = blockIdx.x / n_grp;
+  // shadow rays and extension rays are separate streams: a wave then holds one
+  // kind only (shadow rays all aim at the lights and share most of their walk)
+  const unsigned kind = gpart / kStreamParts;
+  const unsigned part = gpart % kStreamParts;
+  unsigned cnt[kGroup], nq = 0;
+#pragma unroll
+  for (int g = 0; g < kGroup; g++) {
+    cnt[g] = bc[grp * kGroup + g].qcount[parity][kind];
+    nq += cnt[g];
+  }
+  if (part * kBlock >= nq) return;  // whole workgroup has nothing to do
+  if (part == 0 && threadIdx.x < kGroup)
+    bc[grp * kGroup + threadIdx.x].rays[kind] += bc[grp * kGroup + threadIdx.x].qcount[parity][kind];  // only writer
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
     __syncthreads();
   }
-  const bool valid = off + threadIdx.x < nq;
+  unsigned r = part * kBlock + threadIdx.x;  // index in the packed stream of the group
+  const bool valid = r < nq;
   uint32_t slot = 0;
   bool ext = false;
   V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
   if (valid) {
-    uint32_t e = queue[(size_t)seg * kSegment + off + threadIdx.x];
+    unsigned seg = grp * kGroup;
+#pragma unroll
+    for (int g = 0; g < kGroup - 1; g++) {
+      if (r >= cnt[g]) { r -= cnt[g]; seg++; } else break;
+    }
+    uint32_t e = queue[(size_t)seg * kSegment + kind * kLogicBlock + r];
     slot = e & 0x7fffffffu;
     ext = e >> 31;
     o = xyz(p.A[slot]);
@@ -432,9 +453,8 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   }
 
   // Compaction of the emitted rays into this workgroup's queue segment: 64-wide
-  // ballots give each lane its rank inside the wave, LDS combines the waves.  The
-  // workgroup's shadow rays come first, then its extension rays, so traversal
-  // waves are mostly of one kind.
+  // ballots give each lane its rank inside the wave, LDS combines the waves.
+  // Shadow rays fill the first half of the segment, extension rays the second.
   unsigned long long ms = __ballot(has_shadow), me = __ballot(has_ext), ml = __ballot(live),
                      mf = __ballot(unit_finished);
   if (lane_id() == 0) {
@@ -455,13 +475,14 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     unsigned nl = 0, nf = 0;
     for (int w = 0; w < kLogicWaves; w++) { nl += s_count[2][w]; nf += s_count[3][w]; }
     BlockCounters &b = bc[blockIdx.x];
-    b.qcount[parity] = sh_total + ext_total;
-    if (a.first) { b.done = nf; b.vertices = nl; b.rays = 0; b.qcount[parity ^ 1] = 0; }
+    b.qcount[parity][0] = sh_total;
+    b.qcount[parity][1] = ext_total;
+    if (a.first) { b.done = nf; b.vertices = nl; b.rays[0] = 0; b.rays[1] = 0; b.qcount[parity ^ 1][0] = 0; b.qcount[parity ^ 1][1] = 0; }
     else { b.done += nf; b.vertices += nl; }
   }
   uint32_t *seg = queue + (size_t)blockIdx.x * kSegment;
   if (has_shadow) seg[sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
-  if (has_ext) seg[sh_total + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
+  if (has_ext) seg[kLogicBlock + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
 }
 
 // ---- color / spp: src/Render.cpp:661-662 ----
