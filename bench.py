@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", type=int, default=0, help="path pool size (0 = library default)")
+    ap.add_argument("--chunk", type=int, default=0, help="samples per partial sum (0 = default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,7 +125,8 @@ def main():
 
     def step(record):
         st = scene.render_device(W, H, spp, local.data_ptr(), seed=args.seed, part_index=rank,
-                                 part_count=world, tile_cols=tile, profile=True)
+                                 part_count=world, tile_cols=tile, profile=True,
+                                 pool_size=args.pool, chunk_spp=args.chunk)
         if gather is not None:
             gather(local)  # one RCCL gather + column re-ordering on rank 0
         if record:

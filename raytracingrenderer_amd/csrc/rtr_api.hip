@@ -600,7 +600,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
   // upper bound of the pool; the exact size follows from the number of pixels
   // that need sampling (known after k_classify)
-  size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 20);
+  size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 21);
   size_t pool = pool_target + (size_t)a.n_pix;  // lanes*per_pixel never exceeds this
   if (pool > max_units) pool = max_units;
   pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
@@ -706,7 +706,10 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (n_units > 0) {
     // static unit schedule (see k_logic): `lanes` pixel-list entries in flight,
     // `per_pixel` slots sharing the chunks of one entry
-    size_t lanes = a.n_shade < pool_target ? a.n_shade : pool_target;
+    // lanes divides the pixel list into equal passes, so every slot serves the
+    // same number of entries (+-1)
+    size_t passes = ((size_t)a.n_shade + pool_target - 1) / pool_target;
+    size_t lanes = ((size_t)a.n_shade + passes - 1) / passes;
     size_t per_pixel = (pool_target + lanes / 2) / lanes;
     if (per_pixel < 1) per_pixel = 1;
     if (per_pixel > (size_t)a.n_chunks) per_pixel = a.n_chunks;
