@@ -78,7 +78,9 @@ struct Workspace {
 struct rtr_scene {
   int device = 0;
   hipStream_t stream = nullptr;
-  DevBuf<float4> nodes, tris, sphs, lights;
+  hipStream_t stream2 = nullptr;  // second half of the path pool runs here, overlapping the first
+  DevBuf<float4> nodes, tris, sphs, lights, leaves;
+  DevBuf<int32_t> parent;
   DevBuf<int32_t> tri_prim, sph_prim, prim_kind_row, prim_material, light_tris;
   DevBuf<float> tri_area;
   DevBuf<DeviceMaterial> mats;
@@ -111,6 +113,17 @@ int upload(DevBuf<T> &buf, const std::vector<T> &host) {
   if (!host.empty())
     HIP_TRY(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
   return RTR_OK;
+}
+
+// Smallest float T with sqrtf(T) >= r, so that sqrtf(x) < r  <=>  x < T for every x
+// (sqrtf is correctly rounded, hence monotonic).  r <= 0 or NaN: never true -> T = 0.
+float sqrt_threshold(float r) {
+  if (!(r > 0.0f)) return 0.0f;
+  if (std::isinf(r)) return r;
+  float t = (float)((double)r * (double)r);
+  while (sqrtf(t) >= r && t > 0.0f) t = nextafterf(t, -INFINITY);
+  while (sqrtf(t) < r) t = nextafterf(t, INFINITY);
+  return t;
 }
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -231,6 +244,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
 
   // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
   std::vector<float4> nodes;
+  std::vector<int32_t> parent, leaf_nodes;
   bool fast_planes = true;  // precondition of the division-free box test (rtr_trace.hpp)
   if (d->n_nodes > 0) {
     const int n = d->n_nodes;
@@ -289,6 +303,17 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
       nodes[2 * (size_t)i] = lo;
       nodes[2 * (size_t)i + 1] = hi;
     }
+    // parents, and one record per leaf in depth-first order (rtr_trace.hpp: trace_all)
+    parent.assign(n, -1);
+    for (int i = 0; i < n; i++) {
+      int o = order[i];
+      if (d->node_left[o] < 0 && d->node_right[o] < 0) {
+        leaf_nodes.push_back(i);
+      } else {
+        parent[i + 1] = i;
+        parent[i + 1 + size[i + 1]] = i;
+      }
+    }
   }
 
   std::vector<float4> tris(3 * (size_t)d->n_tris), sphs(d->n_spheres);
@@ -301,6 +326,28 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   }
   for (int s = 0; s < d->n_spheres; s++)
     sphs[s] = make_float4(d->sph_c[0][s], d->sph_c[1][s], d->sph_c[2][s], d->sph_r[s]);
+
+  std::vector<float4> leaves(4 * (leaf_nodes.size() + 1), make_float4(0, 0, 0, 0));  // + padding record
+  for (size_t k = 0; k < leaf_nodes.size(); k++) {
+    int32_t node = leaf_nodes[k], leaf;
+    memcpy(&leaf, &nodes[2 * (size_t)node + 1].w, 4);
+    int row = leaf & 0x3fffffff;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+    if (leaf >> 30) {
+      float4 q = sphs[row];
+      r0 = q;
+      r1.x = q.w * q.w;
+      r1.y = sqrt_threshold(q.w);
+    } else {
+      float4 q0 = tris[3 * (size_t)row], q1 = tris[3 * (size_t)row + 1], q2 = tris[3 * (size_t)row + 2];
+      r0 = q0;
+      r1 = make_float4(q1.x - q0.x, q1.y - q0.y, q1.z - q0.z, q1.w);
+      r2 = make_float4(q2.x - q0.x, q2.y - q0.y, q2.z - q0.z, q2.w);
+    }
+    memcpy(&r3.z, &node, 4);
+    memcpy(&r3.w, &leaf, 4);
+    leaves[4 * k] = r0; leaves[4 * k + 1] = r1; leaves[4 * k + 2] = r2; leaves[4 * k + 3] = r3;
+  }
 
   std::vector<DeviceMaterial> mats(d->n_materials);
   for (int m = 0; m < d->n_materials; m++) {
@@ -367,10 +414,16 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     s->stream = nullptr;
     return bail(fail(RTR_ERR_DEVICE, "hipStreamCreate failed"));
   }
+  if (hipStreamCreate(&s->stream2) != hipSuccess) {
+    s->stream2 = nullptr;
+    return bail(fail(RTR_ERR_DEVICE, "hipStreamCreate failed"));
+  }
   int rc;
   if ((rc = upload(s->nodes, nodes))) return bail(rc);
   if ((rc = upload(s->tris, tris))) return bail(rc);
   if ((rc = upload(s->sphs, sphs))) return bail(rc);
+  if ((rc = upload(s->leaves, leaves))) return bail(rc);
+  if ((rc = upload(s->parent, parent))) return bail(rc);
   if ((rc = upload(s->tri_prim, tri_prim))) return bail(rc);
   if ((rc = upload(s->sph_prim, sph_prim))) return bail(rc);
   if ((rc = upload(s->prim_kind_row, prim_kind_row))) return bail(rc);
@@ -392,6 +445,9 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.fast_planes = fast_planes ? 1 : 0;
   s->ds.n_tris = d->n_tris;
   s->ds.n_sphs = d->n_spheres;
+  s->ds.leaves = s->leaves.ptr;
+  s->ds.parent = s->parent.ptr;
+  s->ds.n_leaves = (int32_t)leaf_nodes.size();
   s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs;
   s->dl.light = s->lights.ptr;
   s->dl.light_tris = s->light_tris.ptr;
@@ -407,11 +463,13 @@ void rtr_scene_destroy(rtr_scene *s) {
   DeviceGuard guard(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   s->nodes.release(); s->tris.release(); s->sphs.release(); s->lights.release();
+  s->leaves.release(); s->parent.release();
   s->tri_prim.release(); s->sph_prim.release(); s->prim_kind_row.release();
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();
   for (auto &b : s->io_f) b.release();
   for (auto &b : s->io_i) b.release();
+  if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -652,7 +710,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     }
     spans.clear();
   };
-  auto timed = [&](int kind, auto &&launch) -> hipError_t {
+  auto timed_on = [&](hipStream_t st, int kind, auto &&launch) -> hipError_t {
     Span sp{nullptr, nullptr, kind};
     if (prof) {
       if (!free_spans.empty()) {
@@ -674,6 +732,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     }
     return e;
   };
+  auto timed = [&](int kind, auto &&launch) -> hipError_t { return timed_on(st, kind, launch); };
   const int kTrace = 0, kLogic = 1, kOther = 2;
 
   HIP_TRY(hipMemcpyAsync(ws.cols.ptr, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, st));
@@ -726,28 +785,46 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   uint64_t iters = 0, total_rays = 0, total_vertices = 0;
   if (n_units > 0) {
     const int batch = 16;
-    const unsigned logic_grid = (unsigned)n_blocks;
-    const unsigned trace_grid = (unsigned)(n_blocks / kGroup * kGroupParts);
+    // The pool is driven as two halves on two streams.  Path logic streams state
+    // through HBM while traversal is fp32-issue bound, so one half's traversal
+    // overlaps the other half's logic instead of each waiting for the other.
+    const size_t n_groups = n_blocks / kGroup;
+    const char *exp_streams = getenv("RTR_EXP_STREAMS");
+    const int n_halves = (n_groups >= 2 && !(exp_streams && atoi(exp_streams) == 1)) ? 2 : 1;
+    const size_t grp_begin[3] = {0, n_halves == 2 ? n_groups / 2 : n_groups, n_groups};
+    hipStream_t streams[2] = {st, s->stream2};
+    const char *exp_phase = getenv("RTR_EXP_PHASE");
+    const int phase_mode = exp_phase ? atoi(exp_phase) : 0;
+    hipEvent_t evL[2];
+    HIP_TRY(hipEventCreateWithFlags(&evL[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&evL[1], hipEventDisableTiming));
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
         a.first = iters == 0 ? 1 : 0;
-        HIP_TRY(timed(kLogic, [&] {
-          hipLaunchKernelGGL(k_logic, dim3(logic_grid), dim3(kLogicBlock), 0, st, a, s->ds, s->dl,
-                             s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
-                             ws.partial.ptr, parity);
-        }));
-        HIP_TRY(timed(kTrace, [&] {
-          if (s->lds_geometry)
-            hipLaunchKernelGGL(k_trace_queue<true>, dim3(trace_grid), dim3(kBlock), 0, st, s->ds, pp,
-                               ws.queue.ptr, bc, parity);
-          else
-            hipLaunchKernelGGL(k_trace_queue<false>, dim3(trace_grid), dim3(kBlock), 0, st, s->ds, pp,
-                               ws.queue.ptr, bc, parity);
-        }));
-        trace_launches++;
+        for (int h = 0; h < n_halves; h++) {
+          const unsigned g0 = (unsigned)grp_begin[h], ng = (unsigned)(grp_begin[h + 1] - grp_begin[h]);
+          if (n_halves == 2 && (phase_mode == 2 || (phase_mode == 1 && iters == 0 && h == 1)) && !(iters == 0 && h == 0))
+            HIP_TRY(hipStreamWaitEvent(streams[h], evL[h ^ 1], 0));
+          HIP_TRY(timed_on(streams[h], kLogic, [&] {
+            hipLaunchKernelGGL(k_logic, dim3(ng * kGroup), dim3(kLogicBlock), 0, streams[h], a, s->ds,
+                               s->dl, s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
+                               ws.partial.ptr, parity, (int)(g0 * kGroup));
+          }));
+          if (n_halves == 2 && phase_mode) HIP_TRY(hipEventRecord(evL[h], streams[h]));
+          HIP_TRY(timed_on(streams[h], kTrace, [&] {
+            if (s->lds_geometry)
+              hipLaunchKernelGGL(k_trace_queue<true>, dim3(ng * kGroupParts), dim3(kBlock), 0,
+                                 streams[h], s->ds, pp, ws.queue.ptr, bc, parity, g0);
+            else
+              hipLaunchKernelGGL(k_trace_queue<false>, dim3(ng * kGroupParts), dim3(kBlock), 0,
+                                 streams[h], s->ds, pp, ws.queue.ptr, bc, parity, g0);
+          }));
+          trace_launches++;
+        }
         iters++;
       }
+      if (n_halves == 2) HIP_TRY(hipStreamSynchronize(s->stream2));
       HIP_TRY(hipMemcpyAsync(ws.host_block_counters, bc, n_blocks * sizeof(BlockCounters),
                              hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));

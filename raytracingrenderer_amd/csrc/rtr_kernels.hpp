@@ -104,14 +104,20 @@ k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4
 // Closest hit for the 64 rays of a wave, from staged (LDS) or global geometry;
 // kLds is chosen by the host from the scene's size.  Every lane of the wave must
 // call this (valid = false where there is no ray).
+// Per-wave LDS of the two traversal flavours: small scenes only need the stack of
+// the literal merge-tree fallback.
+struct SmallShared { MergeStack merge; };
+template <bool kLds> struct WaveLds { typedef WaveShared type; };
+template <> struct WaveLds<true> { typedef SmallShared type; };
+
 template <bool kLds>
 RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, bool valid, V3 o, V3 d, V3 dn,
-                         WaveShared &ws) {
-  if (kLds) {
-    LdsGeom g{lds.nodes, lds.tris, lds.sphs};
-    return trace_wave_scan(g, sc.nodes, sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
+                         typename WaveLds<kLds>::type &ws) {
+  if constexpr (kLds) {
+    return trace_all(sc, lds, valid, o, d, dn, ws.merge);
+  } else {
+    return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
   }
-  return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
 }
 
 template <bool kLds>
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(kBlock)
 k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
             int32_t *__restrict__ prim, float *__restrict__ t, float *__restrict__ pos,
             float *__restrict__ nrm) {
-  __shared__ WaveShared wsh[kBlock / 64];
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
@@ -148,7 +154,7 @@ template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir, int n,
                 float4 *__restrict__ hit) {
-  __shared__ WaveShared wsh[kBlock / 64];
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
   if (kLds) {
     stage_scene(sc, lds, threadIdx.x, kBlock);
@@ -165,8 +171,8 @@ k_trace_primary(DeviceScene sc, CameraSetup cam, const float4 *__restrict__ dir,
 template <bool kLds>
 __global__ void __launch_bounds__(kBlock)
 k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
-              BlockCounters *__restrict__ bc, int parity) {
-  __shared__ WaveShared wsh[kBlock / 64];
+              BlockCounters *__restrict__ bc, int parity, unsigned grp_off) {
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
   // workgroup -> (group of kGroup queue segments, part of their concatenation).
   // Workgroups are dealt to the 8 XCDs round-robin.  Numbering (group, part) with
@@ -174,7 +180,7 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
   // XCD; with the part fastest, all the empty last parts landed on one XCD and the
   // partly filled ones on another, idling a quarter of the chip.
   const unsigned n_grp = gridDim.x / kGroupParts;
-  const unsigned grp = blockIdx.x % n_grp;
+  const unsigned grp = grp_off + blockIdx.x % n_grp;
   const unsigned gpart = blockIdx.x / n_grp;
   // shadow rays and extension rays are separate streams: a wave then holds one
   // kind only (shadow rays all aim at the lights and share most of their walk)
@@ -286,9 +292,10 @@ __global__ void __launch_bounds__(kLogicBlock)
 k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
         PixelCache pc, PathPool p, const uint32_t *__restrict__ shade_list,
         uint32_t *__restrict__ queue, BlockCounters *__restrict__ bc, float4 *__restrict__ partial,
-        int parity) {
+        int parity, int block_off) {
   __shared__ unsigned s_count[4][kLogicWaves];
-  const int slot = blockIdx.x * kLogicBlock + threadIdx.x;
+  const int blk = (int)blockIdx.x + block_off;  // the pool may be driven as several launches
+  const int slot = blk * kLogicBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
   const bool in_range = slot < a.pool;
 
@@ -474,13 +481,13 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   if (threadIdx.x == 0) {
     unsigned nl = 0, nf = 0;
     for (int w = 0; w < kLogicWaves; w++) { nl += s_count[2][w]; nf += s_count[3][w]; }
-    BlockCounters &b = bc[blockIdx.x];
+    BlockCounters &b = bc[blk];
     b.qcount[parity][0] = sh_total;
     b.qcount[parity][1] = ext_total;
     if (a.first) { b.done = nf; b.vertices = nl; b.rays[0] = 0; b.rays[1] = 0; b.qcount[parity ^ 1][0] = 0; b.qcount[parity ^ 1][1] = 0; }
     else { b.done += nf; b.vertices += nl; }
   }
-  uint32_t *seg = queue + (size_t)blockIdx.x * kSegment;
+  uint32_t *seg = queue + (size_t)blk * kSegment;
   if (has_shadow) seg[sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
   if (has_ext) seg[kLogicBlock + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
 }

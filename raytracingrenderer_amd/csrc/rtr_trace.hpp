@@ -40,6 +40,11 @@ struct DeviceScene {
   int32_t n_prims;
   int32_t fast_planes;  // 1: every box plane is 0 or has magnitude in [2^-20, 2^20]
   int32_t n_tris, n_sphs;
+  // small scenes only (see trace_all): one record per leaf in depth-first order,
+  // and every node's parent
+  const float4 *leaves;
+  const int32_t *parent;
+  int32_t n_leaves;
 };
 
 // Where traversal reads geometry from.  GlobalGeom gathers from HBM through the
@@ -222,12 +227,27 @@ RTR_DEV float div_corrected(float a, float d, float y) {
   return __builtin_fmaf(r, y, q);
 }
 
+// Two quotients at a time: gfx950 issues packed fp32 multiply / fma (two IEEE
+// operations per lane and instruction) at the rate of the scalar forms, and the
+// two planes of an axis share d and y.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RTR_DEV f32x2 div_corrected2(f32x2 a, float d, float y) {
+  const f32x2 yy = {y, y}, nd = {-d, -d};
+  f32x2 q = a * yy;
+  f32x2 r = __builtin_elementwise_fma(nd, q, a);
+  q = __builtin_elementwise_fma(r, yy, q);
+  r = __builtin_elementwise_fma(nd, q, a);
+  return __builtin_elementwise_fma(r, yy, q);
+}
+
 RTR_DEV bool slab_fast(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
-  float ax = div_corrected(lo.x - o.x, d.x, y.x), bx = div_corrected(hi.x - o.x, d.x, y.x);
-  float ay = div_corrected(lo.y - o.y, d.y, y.y), by = div_corrected(hi.y - o.y, d.y, y.y);
-  float az = div_corrected(lo.z - o.z, d.z, y.z), bz = div_corrected(hi.z - o.z, d.z, y.z);
-  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  const f32x2 px = {lo.x, hi.x}, py = {lo.y, hi.y}, pz = {lo.z, hi.z};
+  const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f32x2 qx = div_corrected2(px - ox, d.x, y.x);
+  const f32x2 qy = div_corrected2(py - oy, d.y, y.y);
+  const f32x2 qz = div_corrected2(pz - oz, d.z, y.z);
+  float tn = fmaxf(fmaxf(fminf(qx.x, qx.y), fminf(qy.x, qy.y)), fminf(qz.x, qz.y));
+  float tf = fminf(fminf(fmaxf(qx.x, qx.y), fmaxf(qy.x, qy.y)), fmaxf(qz.x, qz.y));
   return tn <= tf;
 }
 
@@ -485,6 +505,7 @@ struct LdsScene {
   float4 nodes[2 * kLdsNodes];
   float4 tris[3 * kLdsTris];
   float4 sphs[kLdsSphs];
+  int32_t parent[kLdsNodes];
 };
 RTR_DEV bool fits_lds(const DeviceScene &sc) {
   return sc.n_nodes <= kLdsNodes && sc.n_tris <= kLdsTris && sc.n_sphs <= kLdsSphs;
@@ -493,6 +514,157 @@ RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthrea
   for (int k = tid; k < 2 * sc.n_nodes; k += nthreads) s.nodes[k] = sc.nodes[k];
   for (int k = tid; k < 3 * sc.n_tris; k += nthreads) s.tris[k] = sc.tris[k];
   for (int k = tid; k < sc.n_sphs; k += nthreads) s.sphs[k] = sc.sphs[k];
+  for (int k = tid; k < sc.n_nodes; k += nthreads) s.parent[k] = sc.parent[k];
+}
+
+// ---------------------------------------------------------------------------
+// Closest hit in a scene of a few dozen primitives: test them all.
+//
+// The reference reaches a leaf only through boxes the ray's line crosses, but it
+// culls nothing by distance, and in a scene this small a line crosses most boxes:
+// walking the tree costs more box tests than there are primitives, plus the
+// bookkeeping of a walk.  Its result is  min over {leaves whose ancestors' boxes
+// all pass}  under the left-to-right fold of src/BVH.cpp:75-76.  Here every lane
+//   1. folds ALL leaves in depth-first order with that same rule -- the leaf index
+//      is wave-uniform, so leaf data arrives through the scalar cache in SGPRs, no
+//      lane is ever idle and there is no per-wave queue, atomic or LDS traffic;
+//   2. runs the reference's box test on the winner's own chain of boxes (leaf to
+//      root).  If they all pass, the winner belongs to the reference's candidate
+//      set, and the minimum of a superset that lies in the subset is the subset's
+//      minimum, ties included: an equal-distance later leaf would have replaced it
+//      in step 1 as well.
+// Rays whose winner fails a box (a hit through the 1e-5 slack of the triangle test
+// just outside a box), and rays that met a NaN distance, are re-traced by the
+// literal tree evaluation, one lane at a time.
+//
+// Leaf record, 4 x float4, in depth-first leaf order:
+//   triangle: {p0, n.x} {e1 = p1-p0, n.y} {e2 = p2-p0, n.z} {-, -, bits(node), bits(leaf)}
+//   sphere:   {c, r}    {r*r, T, -, -}    {-}               {-, -, bits(node), bits(leaf)}
+// e1, e2 and r*r are the reference's own fp32 intermediates (src/Trangle.cpp:8-9,
+// src/Sphere.cpp:13), formed once on the host instead of once per ray.  T is the
+// smallest float whose correctly rounded square root is >= r, so that
+// `length(o) < r` (src/Sphere.cpp:6) is `dot(o,o) < T` without the square root.
+struct LeafRecord {
+  float a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1;
+  int node, leaf;
+};
+typedef const LeafRecord __attribute__((address_space(4))) const_leaf;
+
+// (double)x < L for a float x and a double literal L  <=>  x < ceil_to_float(L)
+constexpr float ceil_to_float(double L) {
+  float f = (float)L;
+  if ((double)f >= L) return f;
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u = f > 0 ? u + 1 : u - 1;
+  return __builtin_bit_cast(float, u);
+}
+constexpr float kTriEps = ceil_to_float(-1e-5);   // src/Trangle.cpp:17
+constexpr float kSphEps = ceil_to_float(1e-3);    // src/Sphere.cpp:29
+
+RTR_DEV bool quotient_operand_fast(float n) {
+  float m = fabsf(n);
+  return m == 0.0f || (m >= 9.094947017729282e-13f && m <= 1099511627776.0f);  // 0 or [2^-40, 2^40]
+}
+
+RTR_DEV LeafRecord load_leaf(const const_leaf *tab, int k) {
+  LeafRecord r;
+  r.a0 = tab[k].a0; r.a1 = tab[k].a1; r.a2 = tab[k].a2; r.a3 = tab[k].a3;
+  r.b0 = tab[k].b0; r.b1 = tab[k].b1; r.b2 = tab[k].b2; r.b3 = tab[k].b3;
+  r.c0 = tab[k].c0; r.c1 = tab[k].c1; r.c2 = tab[k].c2; r.c3 = tab[k].c3;
+  r.d0 = tab[k].d0; r.d1 = tab[k].d1; r.node = tab[k].node; r.leaf = tab[k].leaf;
+  return r;
+}
+
+RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid, V3 o, V3 dir,
+                         V3 dn, MergeStack &merge) {
+  const unsigned lane = threadIdx.x & 63u;
+  const const_leaf *tab = (const const_leaf *)sc.leaves;  // uniform index -> scalar loads
+  const int n_leaves = sc.n_leaves;
+  // per-ray invariants of src/Sphere.cpp:10-14
+  const float qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
+  const float qa4 = 4 * qa;
+  // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
+  // when qa is in [0.5, 2] and |n| is zero or in [2^-40, 2^40]
+  const bool a_fast = qa >= 0.5f && qa <= 2.0f;
+  const float ya = 1.0f / qa;
+  HitRec best;
+  best.leaf = -1;
+  best.t = 0; best.b1 = 0; best.b2 = 0;
+  int best_node = -1;
+  bool nan_seen = false;
+  LeafRecord r = load_leaf(tab, 0);  // the table ends with one padding record
+  for (int k = 0; k < n_leaves; k++) {
+    const LeafRecord nx = load_leaf(tab, k + 1);  // in flight while this leaf is tested
+    const int leaf = r.leaf;
+    float t = 0, b1 = 0, b2 = 0;
+    bool hit;
+    if (leaf >> 30) {
+      // Sphere::intersect, src/Sphere.cpp:3-39
+      const V3 oc = o - mk(r.a0, r.a1, r.a2);
+      const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+      const float b = 2 * (oc.x * dn.x + oc.y * dn.y + oc.z * dn.z);
+      const float cc = l2 - r.b0;
+      const float delta = b * b - qa4 * cc;
+      const float sq = sqrtf(delta);
+      const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
+      float t1, t2;
+      const bool slow = !(a_fast && quotient_operand_fast(n1) && quotient_operand_fast(n2)) &&
+                        !(delta < 0);
+      if (__ballot(slow) == 0) {
+        t1 = div_corrected(n1, qa, ya);
+        t2 = div_corrected(n2, qa, ya);
+      } else {
+        t1 = n1 / qa;
+        t2 = n2 / qa;
+      }
+      hit = !(l2 < r.b1) && !(delta < 0) && !(t1 < kSphEps);
+      t = (t2 < 0) ? t1 : t2;
+    } else {
+      // Trangle::intersect, src/Trangle.cpp:3-28
+      const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
+      const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
+      const V3 s = o - p0;
+      const V3 s1 = cross(dn, e2), s2 = cross(s, e1);
+      const float se = dot(s1, e1);
+      const float inv = 1 / se;
+      t = inv * dot(s2, e2);
+      b1 = inv * dot(s1, s);
+      b2 = inv * dot(s2, dn);
+      hit = !(dot(-dir, n) < 0) &&
+            !(t < kTriEps || b1 < kTriEps || b2 < kTriEps || (1 - b1 - b2) < kTriEps);
+    }
+    const bool is_nan = t != t;
+    nan_seen = nan_seen || (hit && is_nan);
+    // src/BVH.cpp:75-76, folded left to right: replaced unless strictly nearer
+    const bool take = hit && !is_nan && !(best.leaf >= 0 && best.t < t);
+    best.t = take ? t : best.t;
+    best.b1 = take ? b1 : best.b1;
+    best.b2 = take ? b2 : best.b2;
+    best.leaf = take ? leaf : best.leaf;
+    best_node = take ? r.node : best_node;
+    r = nx;
+  }
+  // the winner's boxes, leaf to root: Bound3::intersect, src/Bound3.cpp:3-22
+  const bool fast = sc.fast_planes != 0 && fast_ray(o, dn);
+  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+  bool ok = true;
+  for (int node = best_node; node >= 0; node = lds.parent[node]) {
+    const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
+    bool pass;
+    if (fast) pass = slab_fast(lo, hi, o, dn, inv);
+    else pass = slab(lo, hi, o, dn);
+    ok = ok && pass;
+  }
+  unsigned long long need = __ballot(valid && (nan_seen || !ok));
+  if (need) {
+    LdsGeom g{lds.nodes, lds.tris, lds.sphs};
+    while (need) {
+      int l = __ffsll((long long)need) - 1;
+      if ((int)lane == l) best = trace_tree(g, o, dir, dn, merge);
+      need &= need - 1;
+    }
+  }
+  return best;
 }
 
 // Intersection::postion / ::normal of a recorded hit (src/Trangle.cpp:23-24,
