@@ -139,14 +139,26 @@ typedef struct rtr_render_params {
   int32_t pool_size;  /* concurrent paths; <=0: auto */
   int32_t part_index, part_count, tile_cols;
   int32_t profile;    /* 1: bracket every kernel with events on the launch stream */
+  int32_t mode;       /* RTR_MODE_*; 0: chosen from the scene's size */
+  int32_t streams;    /* wavefront mode: 1 = one stream, kernels never overlap; else the pool
+                         is driven as two halves on two streams */
 } rtr_render_params;
+
+/* How the sampling loop (Render::renderPathTracing's spp loop and the recursion
+ * of Render::pathTracing, src/Render.cpp:84-133, :651-664) is run.  Same image
+ * bit for bit in every mode.
+ *   FUSED:     one persistent kernel, one path per lane, path state in registers;
+ *              chosen for scenes small enough to be staged in LDS.
+ *   WAVEFRONT: a pool of paths in HBM, one path-logic and one traversal kernel per
+ *              bounce, rays compacted into queues; chosen for everything else. */
+enum { RTR_MODE_AUTO = 0, RTR_MODE_WAVEFRONT = 1, RTR_MODE_FUSED = 2 };
 
 typedef struct rtr_stats {
   uint64_t samples;        /* width*height*spp of the rendered columns */
   uint64_t rays;           /* closest-hit queries actually traced */
   uint64_t vertices;       /* path vertices shaded */
   uint64_t iterations;     /* wavefront iterations */
-  int32_t chunk_spp, pool_size, n_columns, reserved;
+  int32_t chunk_spp, pool_size, n_columns, mode; /* mode: the RTR_MODE_* that ran */
   double ms_total;         /* first launch -> framebuffer complete */
   double ms_trace, ms_logic, ms_other; /* only with profile=1 */
   uint64_t trace_launches; /* number of traversal-kernel launches */

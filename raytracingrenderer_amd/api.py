@@ -20,6 +20,9 @@ _ip = C.POINTER(C.c_int32)
 _up = C.POINTER(C.c_uint32)
 
 
+MODE_AUTO, MODE_WAVEFRONT, MODE_FUSED = 0, 1, 2  # rtr_render_params.mode (include/rtr.h)
+
+
 class RtrError(RuntimeError):
     pass
 
@@ -30,14 +33,14 @@ class RenderParams(C.Structure):
                 ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_prob", C.c_float),
                 ("chunk_spp", C.c_int32), ("pool_size", C.c_int32),
                 ("part_index", C.c_int32), ("part_count", C.c_int32), ("tile_cols", C.c_int32),
-                ("profile", C.c_int32)]
+                ("profile", C.c_int32), ("mode", C.c_int32), ("streams", C.c_int32)]
 
 
 class Stats(C.Structure):
     """rtr_stats (include/rtr.h)."""
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("vertices", C.c_uint64),
                 ("iterations", C.c_uint64), ("chunk_spp", C.c_int32), ("pool_size", C.c_int32),
-                ("n_columns", C.c_int32), ("reserved", C.c_int32), ("ms_total", C.c_double),
+                ("n_columns", C.c_int32), ("mode", C.c_int32), ("ms_total", C.c_double),
                 ("ms_trace", C.c_double), ("ms_logic", C.c_double), ("ms_other", C.c_double),
                 ("trace_launches", C.c_uint64)]
 
@@ -326,9 +329,10 @@ class HostScene:
         return c
 
     def make_params(self, W, H, spp, seed=0, max_depth=0, rr_prob=0.0, chunk_spp=0, pool_size=0,
-                    part_index=0, part_count=1, tile_cols=8, profile=False):
+                    part_index=0, part_count=1, tile_cols=8, profile=False, mode=MODE_AUTO,
+                    streams=0):
         return RenderParams(W, H, spp, seed, max_depth, rr_prob, chunk_spp, pool_size, part_index,
-                            part_count, tile_cols, 1 if profile else 0)
+                            part_count, tile_cols, 1 if profile else 0, mode, streams)
 
     def render(self, W, H, spp, **kw):
         """rtr_render_pt into host memory: (rgb[n_cols*H,3], Stats)."""

@@ -88,6 +88,7 @@ struct rtr_scene {
   DeviceLights dl{};
   int n_materials = 0;
   bool lds_geometry = false;  // scene small enough for the kernels to stage it in LDS
+  int fused_grid = 0;         // resident workgroups of the fused sampling kernel (0: not queried yet)
   Workspace ws;
   // scratch for the host-pointer entry points
   DevBuf<float> io_f[5];
@@ -673,6 +674,11 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   HIP_TRY(ws.pc_wi.reserve(a.n_pix));
   HIP_TRY(ws.shade_list.reserve(a.n_pix));
   HIP_TRY(ws.partial.reserve(max_units));
+  // mode: one persistent kernel with path state in registers (scenes whose traversal
+  // needs no per-wave queues), or the wavefront loop over a pool of paths in HBM
+  if (prm->mode < 0 || prm->mode > 2) return fail(RTR_ERR_INVALID, "mode must be 0, 1 or 2");
+  const bool fused = prm->mode == RTR_MODE_FUSED || (prm->mode == RTR_MODE_AUTO && s->lds_geometry);
+  if (fused) pool = kLogicBlock * kGroup;  // the wavefront buffers are not used
   for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
   HIP_TRY(ws.queue.reserve(2 * pool));  // one segment of kSegment entries per k_logic workgroup
   HIP_TRY(ws.counters.reserve(1));
@@ -762,7 +768,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
   a.n_shade = ws.host_counters->n_shade;
   a.n_units = (uint32_t)n_units;
-  if (n_units > 0) {
+  if (n_units > 0 && !fused) {
     // static unit schedule (see k_logic): `lanes` pixel-list entries in flight,
     // `per_pixel` slots sharing the chunks of one entry
     // lanes divides the pixel list into equal passes, so every slot serves the
@@ -783,35 +789,55 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   a.pool = (int)pool;
 
   uint64_t iters = 0, total_rays = 0, total_vertices = 0;
-  if (n_units > 0) {
+  if (n_units > 0 && fused) {
+    // as many workgroups as the device keeps resident at once; every lane then
+    // works through its share of the units
+    if (s->fused_grid == 0) {
+      int per_cu = 0, cus = 0;
+      if (s->lds_geometry)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_fused<true>, kBlock, 0));
+      else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_fused<false>, kBlock, 0));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+      if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
+      s->fused_grid = per_cu * cus;
+    }
+    unsigned grid = (unsigned)s->fused_grid;
+    if ((uint64_t)grid * kBlock > n_units) grid = (unsigned)((n_units + kBlock - 1) / kBlock);
+    HIP_TRY(timed(kTrace, [&] {
+      if (s->lds_geometry)
+        hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                           s->mats.ptr, pc, ws.shade_list.ptr, ws.partial.ptr, cnt);
+      else
+        hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                           s->mats.ptr, pc, ws.shade_list.ptr, ws.partial.ptr, cnt);
+    }));
+    trace_launches++;
+    iters = 1;
+    HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    total_rays = ws.host_counters->rays;
+    total_vertices = ws.host_counters->vertices;
+  } else if (n_units > 0) {
     const int batch = 16;
-    // The pool is driven as two halves on two streams.  Path logic streams state
-    // through HBM while traversal is fp32-issue bound, so one half's traversal
+    // The pool is driven as two halves on two streams (streams = 2).  Path logic is
+    // bound by HBM latency and traversal by fp32 issue, so one half's traversal
     // overlaps the other half's logic instead of each waiting for the other.
     const size_t n_groups = n_blocks / kGroup;
-    const char *exp_streams = getenv("RTR_EXP_STREAMS");
-    const int n_halves = (n_groups >= 2 && !(exp_streams && atoi(exp_streams) == 1)) ? 2 : 1;
+    const int n_halves = (n_groups >= 2 && prm->streams != 1) ? 2 : 1;
     const size_t grp_begin[3] = {0, n_halves == 2 ? n_groups / 2 : n_groups, n_groups};
     hipStream_t streams[2] = {st, s->stream2};
-    const char *exp_phase = getenv("RTR_EXP_PHASE");
-    const int phase_mode = exp_phase ? atoi(exp_phase) : 0;
-    hipEvent_t evL[2];
-    HIP_TRY(hipEventCreateWithFlags(&evL[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&evL[1], hipEventDisableTiming));
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
         a.first = iters == 0 ? 1 : 0;
         for (int h = 0; h < n_halves; h++) {
           const unsigned g0 = (unsigned)grp_begin[h], ng = (unsigned)(grp_begin[h + 1] - grp_begin[h]);
-          if (n_halves == 2 && (phase_mode == 2 || (phase_mode == 1 && iters == 0 && h == 1)) && !(iters == 0 && h == 0))
-            HIP_TRY(hipStreamWaitEvent(streams[h], evL[h ^ 1], 0));
           HIP_TRY(timed_on(streams[h], kLogic, [&] {
             hipLaunchKernelGGL(k_logic, dim3(ng * kGroup), dim3(kLogicBlock), 0, streams[h], a, s->ds,
                                s->dl, s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
                                ws.partial.ptr, parity, (int)(g0 * kGroup));
           }));
-          if (n_halves == 2 && phase_mode) HIP_TRY(hipEventRecord(evL[h], streams[h]));
           HIP_TRY(timed_on(streams[h], kTrace, [&] {
             if (s->lds_geometry)
               hipLaunchKernelGGL(k_trace_queue<true>, dim3(ng * kGroupParts), dim3(kBlock), 0,
@@ -856,7 +882,8 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     stats->vertices = total_vertices;
     stats->iterations = iters;
     stats->chunk_spp = a.chunk_spp;
-    stats->pool_size = a.pool;
+    stats->pool_size = fused ? 0 : a.pool;
+    stats->mode = fused ? RTR_MODE_FUSED : RTR_MODE_WAVEFRONT;
     stats->n_columns = a.n_cols;
     stats->ms_trace = ms_kind[kTrace];
     stats->ms_logic = ms_kind[kLogic];

@@ -60,7 +60,8 @@ enum : uint32_t { kLive = 1u, kHasShadow = 2u, kHasExt = 4u, kHasUnit = 8u };
 
 struct Counters {
   unsigned int n_shade;  // pixels that need sampling (k_classify)
-  unsigned int pad[3];
+  unsigned int pad;
+  unsigned long long vertices, rays;  // totals of the fused sampling kernel
 };
 
 // The render loop uses no global atomics.  Every k_logic workgroup owns one
@@ -287,6 +288,60 @@ k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats
   }
 }
 
+// ---- shading of one path vertex: src/Render.cpp:90-116 ----
+// Next-event estimation (light sample, shadow ray) and, if Russian roulette lets
+// the path go on, the BSDF sample (extension ray).  Random numbers are drawn in
+// the reference's order.
+struct Emit {
+  bool has_shadow, has_ext;
+  V3 l;          // shadow ray direction, unit(light point - pos)
+  V3 light_pos;  // the sampled light point
+  V3 weight;     // Le * f * cos * cos'
+  float light_pdf;
+  V3 w1;         // extension ray direction
+  V3 beta_next;  // path weight after the bounce (zero if the path stops here)
+};
+
+RTR_DEV void shade_vertex(const RenderArgs &a, const DeviceScene &sc, const DeviceLights &L,
+                          const DeviceMaterial *__restrict__ mats, V3 pos, V3 N, V3 wi, V3 beta,
+                          uint32_t mat, uint32_t gpix, uint32_t k, uint32_t depth, Emit &e) {
+  DeviceMaterial dm = mats[mat];
+  const V3 ui = unit(wi), un = unit(N);  // shared by the two evaluations below
+  VertexStream rng(a.seed, gpix, k, depth);
+  LightSample ls;
+  sample_light(sc, L, rng, ls);
+  e.has_shadow = false;
+  e.has_ext = false;
+  e.light_pos = ls.pos;
+  e.light_pdf = ls.pdf;
+  if (ls.pdf > 0) {
+    V3 l = unit(ls.pos - pos);
+    V3 l2 = unit(l);
+    int lprim = (ls.leaf >> 30) ? sc.sph_prim[ls.leaf & 0x3fffffff] : sc.tri_prim[ls.leaf];
+    V3 Le = xyz(mats[sc.prim_material[lprim]].e_kind);
+    e.weight = Le * mat_eval_units(dm, ui, l2, un) * dot(N, l2) * dot(unit(ls.nrm), -l2);
+    e.l = l;
+    e.has_shadow = true;
+  }
+  if (rng.next() < a.rr) {
+    V3 wo;
+    if (mat_kind(dm) == 1) {
+      wo = mat_mirror(wi, N);
+    } else {
+      float u1 = rng.next();
+      float u2 = rng.next();
+      wo = mat_sample_uv(N, u1, u2);
+    }
+    float pdf = mat_pdf(dm);
+    V3 w1 = unit(wo);
+    e.beta_next = beta * mat_eval_units(dm, ui, unit(w1), un) * dot(N, w1) / pdf / a.rr;
+    e.w1 = w1;
+    e.has_ext = true;
+  } else {
+    e.beta_next = mk(0, 0, 0);
+  }
+}
+
 // ---- one wavefront iteration of path logic ----
 __global__ void __launch_bounds__(kLogicBlock)
 k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
@@ -413,38 +468,16 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   // shade the current vertex: src/Render.cpp:90-116
   bool has_shadow = false, has_ext = false;
   if (live) {
-    DeviceMaterial dm = mats[mat];
-    VertexStream rng(a.seed, gpix, k, depth);
-    LightSample ls;
-    sample_light(sc, L, rng, ls);
-    if (ls.pdf > 0) {
-      V3 l = unit(ls.pos - pos);
-      V3 l2 = unit(l);
-      int lprim = (ls.leaf >> 30) ? sc.sph_prim[ls.leaf & 0x3fffffff] : sc.tri_prim[ls.leaf];
-      V3 Le = xyz(mats[sc.prim_material[lprim]].e_kind);
-      V3 w = Le * mat_eval(dm, wi, l2, N) * dot(N, l2) * dot(unit(ls.nrm), -l2);
-      p.G[slot] = pack(w, ls.pdf);
-      p.J[slot] = pack(l, 0.0f);
-      has_shadow = true;
+    Emit e;
+    shade_vertex(a, sc, L, mats, pos, N, wi, beta, mat, gpix, k, depth, e);
+    has_shadow = e.has_shadow;
+    has_ext = e.has_ext;
+    if (has_shadow) {
+      p.G[slot] = pack(e.weight, e.light_pdf);
+      p.J[slot] = pack(e.l, 0.0f);
     }
-    if (rng.next() < a.rr) {
-      V3 wo;
-      if (mat_kind(dm) == 1) {
-        wo = mat_mirror(wi, N);
-      } else {
-        float u1 = rng.next();
-        float u2 = rng.next();
-        wo = mat_sample_uv(N, u1, u2);
-      }
-      float pdf = mat_pdf(dm);
-      V3 w1 = unit(wo);
-      V3 bn = beta * mat_eval(dm, wi, unit(w1), N) * dot(N, w1) / pdf / a.rr;
-      p.I[slot] = pack(bn, gpix);
-      p.K[slot] = pack(w1, 0.0f);
-      has_ext = true;
-    } else {
-      p.I[slot] = pack(mk(0, 0, 0), gpix);
-    }
+    p.I[slot] = pack(e.beta_next, gpix);
+    if (has_ext) p.K[slot] = pack(e.w1, 0.0f);
     flags = (flags & ~(kHasShadow | kHasExt)) | (has_shadow ? kHasShadow : 0u) |
             (has_ext ? kHasExt : 0u);
     p.A[slot] = pack(pos, mat);
@@ -453,7 +486,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     p.D[slot] = pack(beta, k);
     p.E[slot] = pack(Lp, k_end);
     if (unit_changed) p.F[slot] = pack(acc, unit_id);
-    p.Hh[slot] = pack(ls.pos, flags);
+    p.Hh[slot] = pack(e.light_pos, flags);
   } else if (in_range && (unit_changed || a.first)) {
     p.F[slot] = pack(acc, unit_id);
     p.Hh[slot] = pack(mk(0, 0, 0), 0u);
@@ -490,6 +523,152 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   uint32_t *seg = queue + (size_t)blk * kSegment;
   if (has_shadow) seg[sh_before + __popcll(ms & lanes_below())] = (uint32_t)slot;
   if (has_ext) seg[kLogicBlock + ext_before + __popcll(me & lanes_below())] = (uint32_t)slot | 0x80000000u;
+}
+
+// ---- the whole sampling loop in one kernel ----
+// For scenes whose traversal needs no per-wave queues (trace_any with staged
+// geometry), path state never has to leave the registers: every lane carries one
+// path, shades its vertex, traces the shadow ray and the extension ray itself and
+// moves on to the next sample or work unit when the path ends.  All lanes of a
+// wave do the same thing in every round (shade, trace, trace), whatever the depth
+// of their paths, so there is nothing to sort or compact, and no path state,
+// ray queue or hit record goes through HBM.
+//
+// Units are dealt statically: with T lanes in the grid, lane g takes units
+// g, g + T, g + 2T, ...; unit u is (chunk u / n_shade, pixel-list entry u % n_shade),
+// so the lanes of a wave start on neighbouring pixels.  The image is the same as
+// the wavefront loop's, bit for bit: a unit's samples are summed in order by
+// whichever lane owns it.
+template <bool kLds>
+RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const HitRec &h, V3 o, V3 dn,
+                           V3 &pos, V3 &nrm) {
+  const float4 *tris = kLds ? lds.tris : sc.tris;
+  const float4 *sphs = kLds ? lds.sphs : sc.sphs;
+  int row = h.leaf & 0x3fffffff;
+  if (h.leaf >> 30) {
+    float4 q = sphs[row];
+    pos = o + dn * h.t;
+    nrm = unit(pos - xyz(q));
+  } else {
+    float4 q0 = tris[3 * row], q1 = tris[3 * row + 1], q2 = tris[3 * row + 2];
+    pos = xyz(q0) * (1 - h.b1 - h.b2) + xyz(q1) * h.b1 + xyz(q2) * h.b2;
+    nrm = mk(q0.w, q1.w, q2.w);
+  }
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock)
+k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
+               PixelCache pc, const uint32_t *__restrict__ shade_list, float4 *__restrict__ partial,
+               Counters *__restrict__ fc) {
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
+  __shared__ LdsScene lds;
+  if (kLds) {
+    stage_scene(sc, lds, threadIdx.x, kBlock);
+    __syncthreads();
+  }
+  typename WaveLds<kLds>::type &ws = wsh[threadIdx.x >> 6];
+  const unsigned long long n_lanes = (unsigned long long)gridDim.x * kBlock;
+  unsigned long long u = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;  // next unit of this lane
+
+  // the unit: pixel, its first vertex (the same for all its samples), sample range, sum
+  V3 fpos = mk(0, 0, 0), fN = fpos, fwi = fpos, acc = fpos;
+  uint32_t fmat = 0, gpix = 0, lp = 0, chunk = 0, k = 0, k_end = 0;
+  bool has_unit = false;
+  // the path
+  V3 pos = fpos, N = fpos, wi = fpos, beta = fpos, Lp = fpos;
+  uint32_t mat = 0, depth = 0;
+  bool live = false;
+  uint32_t n_vertices = 0, n_rays = 0;
+
+  for (;;) {
+    if (!live) {
+      if (has_unit && k >= k_end) {
+        partial[(size_t)chunk * a.n_pix + lp] = pack(acc, 0.0f);
+        has_unit = false;
+      }
+      if (!has_unit && u < a.n_units) {
+        const uint32_t entry = (uint32_t)(u % a.n_shade);
+        chunk = (uint32_t)(u / a.n_shade);
+        u += n_lanes;
+        lp = shade_list[entry];
+        const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
+        fpos = xyz(pm); fmat = wbits(pm);
+        fN = xyz(pn);
+        fwi = xyz(pw); gpix = wbits(pw);
+        k = chunk * (uint32_t)a.chunk_spp;
+        k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+        acc = mk(0, 0, 0);
+        has_unit = true;
+      }
+      if (has_unit) {
+        pos = fpos; N = fN; wi = fwi; mat = fmat;
+        beta = mk(1, 1, 1);
+        Lp = mk(0, 0, 0);
+        depth = 0;
+        live = true;
+      }
+    }
+    if (__ballot(live) == 0) break;
+
+    Emit e;
+    e.has_shadow = false; e.has_ext = false;
+    e.l = mk(1, 1, 1); e.w1 = mk(1, 1, 1);
+    e.light_pos = mk(0, 0, 0); e.weight = mk(0, 0, 0); e.beta_next = mk(0, 0, 0);
+    e.light_pdf = 0;
+    if (live) {
+      shade_vertex(a, sc, L, mats, pos, N, wi, beta, mat, gpix, k, depth, e);
+      n_vertices++;
+      n_rays += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
+    }
+    const V3 ln = unit(e.l), wn = unit(e.w1);
+    const HitRec hs = trace_any<kLds>(sc, lds, e.has_shadow, pos, e.l, ln, ws);
+    const HitRec he = trace_any<kLds>(sc, lds, e.has_ext, pos, e.w1, wn, ws);
+    if (live) {
+      // next-event result: src/Render.cpp:95-107.  A miss fails the distance test
+      // like the reference's `testInter.hit` does.
+      if (e.has_shadow && hs.leaf >= 0) {
+        V3 hp, hn;
+        hit_point_any<kLds>(sc, lds, hs, pos, ln, hp, hn);
+        float dl = length(hp - e.light_pos);
+        if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
+          V3 term = e.weight / (hs.t * hs.t) / e.light_pdf;
+          Lp = Lp + beta * term;
+        }
+      }
+      // extension result: src/Render.cpp:117-125
+      bool cont = false;
+      if (e.has_ext && he.leaf >= 0) {
+        int m2 = sc.prim_material[hit_prim(sc, he)];
+        if (!mat_emissive(mats[m2]) && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
+          V3 hp, hn;
+          hit_point_any<kLds>(sc, lds, he, pos, wn, hp, hn);
+          beta = e.beta_next;
+          wi = -wn;
+          N = unit(hn);
+          pos = hp;
+          mat = (uint32_t)m2;
+          depth++;
+          cont = true;
+        }
+      }
+      if (!cont) {
+        acc = acc + Lp;  // color = color + pathTracing(...), src/Render.cpp:659
+        k++;
+        live = false;
+      }
+    }
+  }
+  // statistics: one atomic pair per wave
+  unsigned long long nv = n_vertices, nr = n_rays;
+  for (int off = 32; off > 0; off >>= 1) {
+    nv += __shfl_down(nv, off);
+    nr += __shfl_down(nr, off);
+  }
+  if (lane_id() == 0) {
+    atomicAdd(&fc->vertices, nv);
+    atomicAdd(&fc->rays, nr);
+  }
 }
 
 // ---- color / spp: src/Render.cpp:661-662 ----

@@ -63,31 +63,36 @@ RTR_DEV float smith_g(float roughness, V3 N, V3 V, V3 L) {
   return g1 * g2;
 }
 
-// Material::eval, src/Material.cpp:66-95
-RTR_DEV V3 mat_eval(const DeviceMaterial &m, V3 wi, V3 wo, V3 n) {
+// Material::eval, src/Material.cpp:66-95.  The reference normalises wi, wo and n
+// again in every branch; ui = unit(wi) and un = unit(n) are passed in so that a
+// vertex which evaluates its material twice forms them once.
+RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un) {
   V3 res = mk(0, 0, 0);
   int kind = mat_kind(m);
   V3 kd = xyz(m.kd_ior);
+  const V3 uo = unit(wo);
   if (kind == 0) {
-    float c = dot(unit(wo), unit(n));
+    float c = dot(uo, un);
     float f = c > 0.0f ? (float)(1.0f / kPi) : 0.0f;
     res = kd * f;
   } else if (kind == 1) {
-    V3 h = unit(wi) + unit(wo);
+    V3 h = ui + uo;
     h = unit(h);
-    V3 N = unit(n);
-    res = ((double)dot(h, N) > (double)1.0f - 1e-3) ? kd : mk(0, 0, 0);
+    res = ((double)dot(h, un) > (double)1.0f - 1e-3) ? kd : mk(0, 0, 0);
   } else {
     V3 ks = xyz(m.ks_rough);
     float rough = m.ks_rough.w;
-    float kr = fresnel_kr(unit(wi), unit(n), m.kd_ior.w);
-    float d = ggx_d(rough, unit(n), unit(unit(wi) + unit(wo)));
-    float g = smith_g(rough, unit(n), unit(wi), unit(wo));
-    float co = dot(unit(wo), unit(n));
-    float ci = dot(unit(wi), unit(n));
+    float kr = fresnel_kr(ui, un, m.kd_ior.w);
+    float d = ggx_d(rough, un, unit(ui + uo));
+    float g = smith_g(rough, un, ui, uo);
+    float co = dot(uo, un);
+    float ci = dot(ui, un);
     res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + kd * (1 - kr) / (float)kPi;
   }
   return res;
+}
+RTR_DEV V3 mat_eval(const DeviceMaterial &m, V3 wi, V3 wo, V3 n) {
+  return mat_eval_units(m, unit(wi), wo, unit(n));
 }
 
 // Material::pdf, src/Material.cpp:149-168

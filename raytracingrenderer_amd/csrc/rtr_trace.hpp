@@ -605,20 +605,25 @@ RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid,
       const float b = 2 * (oc.x * dn.x + oc.y * dn.y + oc.z * dn.z);
       const float cc = l2 - r.b0;
       const float delta = b * b - qa4 * cc;
-      const float sq = sqrtf(delta);
-      const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
-      float t1, t2;
-      const bool slow = !(a_fast && quotient_operand_fast(n1) && quotient_operand_fast(n2)) &&
-                        !(delta < 0);
-      if (__ballot(slow) == 0) {
-        t1 = div_corrected(n1, qa, ya);
-        t2 = div_corrected(n2, qa, ya);
-      } else {
-        t1 = n1 / qa;
-        t2 = n2 / qa;
+      // most waves have no ray that reaches this sphere: the square root and the
+      // two quotients are only formed when some lane needs them
+      const bool reach = valid && !(l2 < r.b1) && !(delta < 0);
+      hit = false;
+      if (__ballot(reach) != 0) {
+        const float sq = sqrtf(delta);
+        const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
+        float t1, t2;
+        const bool slow = reach && !(a_fast && quotient_operand_fast(n1) && quotient_operand_fast(n2));
+        if (__ballot(slow) == 0) {
+          t1 = div_corrected(n1, qa, ya);
+          t2 = div_corrected(n2, qa, ya);
+        } else {
+          t1 = n1 / qa;
+          t2 = n2 / qa;
+        }
+        hit = reach && !(t1 < kSphEps);
+        t = (t2 < 0) ? t1 : t2;
       }
-      hit = !(l2 < r.b1) && !(delta < 0) && !(t1 < kSphEps);
-      t = (t2 < 0) ? t1 : t2;
     } else {
       // Trangle::intersect, src/Trangle.cpp:3-28
       const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);

@@ -453,6 +453,8 @@ void Render::renderPathTracing(Scene &scene, const unsigned int &imageWidth,
   p.part_count = options.part_count;
   p.tile_cols = options.tile_cols;
   p.profile = options.profile ? 1 : 0;
+  p.mode = options.mode;
+  p.streams = options.streams;
   int32_t n_cols = 0;
   rtr_check(rtr_partition_columns(p.width, p.part_index, p.part_count, p.tile_cols, &n_cols, nullptr),
             "rtr_partition_columns");
@@ -661,6 +663,8 @@ int rtrh_render(void *hs, unsigned W, unsigned H, unsigned spp, const char *file
       h->render.options.part_count = opt->part_count > 0 ? opt->part_count : 1;
       h->render.options.tile_cols = opt->tile_cols;
       h->render.options.profile = opt->profile != 0;
+      h->render.options.mode = opt->mode;
+      h->render.options.streams = opt->streams;
     }
     h->render.renderPathTracing(*h->scene, W, H, spp, file ? std::string(file) : std::string());
     const std::vector<Vector3f> &b = h->render.getBuffer();

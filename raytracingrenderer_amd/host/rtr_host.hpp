@@ -251,6 +251,7 @@ struct RenderOptions {  // what the reference hard-codes, see rtr_render_params
   int chunk_spp = 0, pool_size = 0;
   int part_index = 0, part_count = 1, tile_cols = 8;
   bool profile = false;
+  int mode = 0, streams = 0;  // rtr_render_params::mode / ::streams
 };
 
 class Render {

@@ -11,7 +11,7 @@ import csv,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
 for r in csv.DictReader(open("$R/gpurun_out/pmc/p_counter_collection.csv")):
     k=r["Kernel_Name"].split("(")[0]
-    if "k_trace_queue" not in k and "k_logic" not in k: continue
+    if "k_trace_queue" not in k and "k_logic" not in k and "k_render_fused" not in k: continue
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
 for k in agg:
     print(k, len(n[k]))
