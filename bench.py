@@ -28,7 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # reference's own arithmetic: 25.6 box tests x 21 flop + 3.4 triangle tests x
 # 100 flop + 0.75 sphere tests x 65 flop, and 36 streamed bytes (ray in 28, hit
 # out 8).  Counts per query were measured on the reference's traversal.
+# Shading one path vertex (light sample, two BSDF evaluations, BSDF sample): 200 flop.
 FLOP_PER_QUERY = 25.6 * 21 + 3.4 * 100 + 0.75 * 65
+FLOP_PER_VERTEX = 200.0
 BYTES_PER_QUERY = 36.0
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X vector fp32, FMA counted as 2 flop
 PEAK_HBM_GBS = 8000.0
@@ -88,6 +90,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=0, help="path pool size (0 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="samples per partial sum (0 = default)")
+    ap.add_argument("--mode", type=int, default=0,
+                    help="0: library default (fused kernel for this scene), 1: wavefront, 2: fused")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="wavefront mode: 1 = kernels never overlap, else two streams")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,12 +127,14 @@ def main():
     gather = ColumnGather(torch, dist, W, H, rank, world, tile, dev, dst=0) if world > 1 else None
 
     agg = {"rays": 0, "vertices": 0, "ms_trace": 0.0, "ms_logic": 0.0, "ms_other": 0.0,
-           "trace_launches": 0, "iterations": 0}
+           "ms_fused": 0.0, "trace_launches": 0, "fused_launches": 0, "iterations": 0,
+           "samples": 0, "mode": 0}
 
     def step(record):
         st = scene.render_device(W, H, spp, local.data_ptr(), seed=args.seed, part_index=rank,
                                  part_count=world, tile_cols=tile, profile=True,
-                                 pool_size=args.pool, chunk_spp=args.chunk)
+                                 pool_size=args.pool, chunk_spp=args.chunk, mode=args.mode,
+                                 streams=args.streams)
         if gather is not None:
             gather(local)  # one RCCL gather + column re-ordering on rank 0
         if record:
@@ -135,8 +143,12 @@ def main():
             agg["ms_trace"] += st.ms_trace
             agg["ms_logic"] += st.ms_logic
             agg["ms_other"] += st.ms_other
+            agg["ms_fused"] += st.ms_fused
             agg["trace_launches"] += st.trace_launches
+            agg["fused_launches"] += st.fused_launches
             agg["iterations"] += st.iterations
+            agg["samples"] += st.samples
+            agg["mode"] = st.mode
         return st
 
     def fence():
@@ -167,18 +179,32 @@ def main():
     if rank == 0:
         samples = float(W) * H * spp * args.steps
         value = samples / elapsed / 1e6
-        # dominant kernel: the queue traversal kernel (k_trace_queue).  Average launch
-        # duration from HIP events on the library's own launch stream (rank 0's launches).
-        launches = max(agg["trace_launches"], 1)
-        avg_ms = agg["ms_trace"] / launches
-        rays_per_launch = agg["rays"] / launches
-        tflops = FLOP_PER_QUERY * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # Dominant kernel, timed with HIP events on the library's own launch stream
+        # (rank 0's launches).  Fused mode: k_render_fused, one launch per step, does
+        # all sampling (shading and both closest-hit queries of every vertex).
+        # Wavefront mode: k_trace_queue, one launch per bounce (the primary-ray launch
+        # of each step is in the average too, with its own ray count).
+        fused = agg["mode"] == 2
+        if fused:
+            kernel = "k_render_fused"
+            launches = max(agg["fused_launches"], 1)
+            avg_ms = agg["ms_fused"] / launches
+            queries = (agg["rays"] - agg["samples"] / spp) / launches  # rays minus the primary rays
+            flop_per_launch = FLOP_PER_QUERY * queries + FLOP_PER_VERTEX * agg["vertices"] / launches
+        else:
+            kernel = "k_trace_queue"
+            launches = max(agg["trace_launches"], 1)
+            avg_ms = agg["ms_trace"] / launches
+            queries = agg["rays"] / launches
+            flop_per_launch = FLOP_PER_QUERY * queries
+        rays_per_launch = queries
+        tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         gbs = BYTES_PER_QUERY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_trace_queue_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -196,19 +222,22 @@ def main():
             "iterations_per_step_rank0": agg["iterations"] / args.steps,
             "rays_per_sample": rays_total / samples,
             "vertices_per_sample": vert_total / samples,
-            "kernel_ms_per_step_rank0": {"trace": agg["ms_trace"] / args.steps,
+            "mode": "fused" if fused else "wavefront",
+            "kernel_ms_per_step_rank0": {"fused": agg["ms_fused"] / args.steps,
+                                         "trace": agg["ms_trace"] / args.steps,
                                          "logic": agg["ms_logic"] / args.steps,
                                          "other": agg["ms_other"] / args.steps},
-            "roofline": {"kernel": "k_trace_queue", "bound": "valu", "achieved": tflops,
+            "roofline": {"kernel": kernel, "bound": "valu", "achieved": tflops,
                          "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_FP32_VECTOR_TFLOPS,
                          "traffic": traffic,
                          "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch,
-                         "flop_per_query": FLOP_PER_QUERY,
+                         "flop_per_query": FLOP_PER_QUERY, "flop_per_vertex": FLOP_PER_VERTEX,
                          "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_query": BYTES_PER_QUERY},
-                         "note": "fp32 VALU-issue bound (57-node scene is cache resident); parity "
-                                 "forbids FMA, so at most half of the FMA-counted peak is reachable"},
+                         "note": "fp32 VALU-issue bound (the 37-node scene sits in LDS and the "
+                                 "scalar cache); parity forbids FMA contraction, so at most half "
+                                 "of the FMA-counted peak is reachable"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

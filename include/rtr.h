@@ -160,8 +160,11 @@ typedef struct rtr_stats {
   uint64_t iterations;     /* wavefront iterations */
   int32_t chunk_spp, pool_size, n_columns, mode; /* mode: the RTR_MODE_* that ran */
   double ms_total;         /* first launch -> framebuffer complete */
-  double ms_trace, ms_logic, ms_other; /* only with profile=1 */
+  double ms_trace, ms_logic, ms_other; /* only with profile=1: traversal kernels, path-logic
+                                          kernels, everything else */
   uint64_t trace_launches; /* number of traversal-kernel launches */
+  double ms_fused;         /* only with profile=1: the fused sampling kernel */
+  uint64_t fused_launches; /* 1 in RTR_MODE_FUSED (0 when no pixel needed sampling) */
 } rtr_stats;
 
 const char *rtr_last_error(void);

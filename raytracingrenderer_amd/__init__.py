@@ -13,6 +13,6 @@ benchmark and Python callers.  It has no CPU implementation of anything: if the
 libraries are missing, importing :mod:`raytracingrenderer_amd.api` raises.
 """
 from .api import (  # noqa: F401
-    DIFFUSE, MICROFACET, SPECULAR, HostScene, RenderParams, RtrError, Stats, default_scene,
+    DIFFUSE, MICROFACET, MODE_AUTO, MODE_FUSED, MODE_WAVEFRONT, SPECULAR, HostScene, RenderParams, RtrError, Stats, default_scene,
     device_count, hip_lib, host_lib, partition_columns,
 )

@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("iterations", C.c_uint64), ("chunk_spp", C.c_int32), ("pool_size", C.c_int32),
                 ("n_columns", C.c_int32), ("mode", C.c_int32), ("ms_total", C.c_double),
                 ("ms_trace", C.c_double), ("ms_logic", C.c_double), ("ms_other", C.c_double),
-                ("trace_launches", C.c_uint64)]
+                ("trace_launches", C.c_uint64), ("ms_fused", C.c_double),
+                ("fused_launches", C.c_uint64)]
 
 
 class Camera(C.Structure):

@@ -430,6 +430,9 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     if (a.first) {
       entry = (unsigned)slot % lanes;
       chunk = (unsigned)slot / lanes;
+      // the pool is rounded up to whole workgroup groups: slots past lanes * per_pixel
+      // get nothing (their chunk sequence would repeat that of the first slot row)
+      if (chunk >= per_pixel) chunk = nch;
     } else {
       entry = unit_id / nch;
       chunk = unit_id - entry * nch + per_pixel;

@@ -213,10 +213,18 @@ def _assert_images_equal(got, want):
     assert eq.all(), (np.nonzero(~eq.all(1))[0][:10], got[~eq.all(1)][:3], want[~eq.all(1)][:3])
 
 
+# the sampling loop has two implementations (rtr_render_params.mode); the wavefront
+# one can drive its pool on one stream or two
+MODES = [dict(mode=2), dict(mode=1, streams=1), dict(mode=1, streams=2)]
+MODE_IDS = ["fused", "wavefront-1-stream", "wavefront-2-streams"]
+
+
+@pytest.mark.parametrize("how", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("W,H,spp,chunk", [(64, 48, 8, 3), (33, 17, 5, 0), (96, 96, 16, 4)])
-def test_render_bit_exact_vs_checker(scenes, W, H, spp, chunk):
+def test_render_bit_exact_vs_checker(scenes, W, H, spp, chunk, how):
     O, so, sg = scenes
-    rgb, st = sg.render(W, H, spp, seed=7, chunk_spp=chunk)
+    rgb, st = sg.render(W, H, spp, seed=7, chunk_spp=chunk, **how)
+    assert st.mode == how["mode"]
     want, stats = O.render(so, W, H, spp, seed=7, chunk_spp=st.chunk_spp)
     _assert_images_equal(rgb, want)
     assert st.samples == W * H * spp == stats[0]
@@ -228,9 +236,12 @@ def test_render_bit_exact_vs_checker(scenes, W, H, spp, chunk):
 def test_render_independent_of_pool_and_partition(rt, scenes):
     O, so, sg = scenes
     W, H, spp = 80, 40, 6
-    full, _ = sg.render(W, H, spp, seed=3, chunk_spp=2)
-    small_pool, _ = sg.render(W, H, spp, seed=3, chunk_spp=2, pool_size=512)
-    _assert_images_equal(small_pool, full)
+    full, st = sg.render(W, H, spp, seed=3, chunk_spp=2)
+    assert st.mode == rt.MODE_FUSED  # what the default scene gets by default
+    for pool in (512, 4096):
+        small_pool, st = sg.render(W, H, spp, seed=3, chunk_spp=2, pool_size=pool, mode=rt.MODE_WAVEFRONT)
+        assert st.mode == rt.MODE_WAVEFRONT
+        _assert_images_equal(small_pool, full)
     R = 3
     out = np.zeros_like(full).reshape(W, H, 3)
     for r in range(R):
@@ -256,11 +267,12 @@ def test_render_variant_scene_depth_cap_and_rr(rt):
     so = O.build_scene(spec)
     O.set_math(so, portable=True)
     sg = rt.HostScene.from_spec(spec)
-    rgb, st = sg.render(48, 48, 6, seed=11, max_depth=16, rr_prob=0.95, chunk_spp=2)
     want, stats = O.render(so, 48, 48, 6, seed=11, max_depth=16, rr_prob=0.95, chunk_spp=2)
-    _assert_images_equal(rgb, want)
-    assert st.vertices == stats[3]
-    assert st.vertices / st.samples > 4  # long paths
+    for how in MODES:
+        rgb, st = sg.render(48, 48, 6, seed=11, max_depth=16, rr_prob=0.95, chunk_spp=2, **how)
+        _assert_images_equal(rgb, want)
+        assert st.vertices == stats[3]
+        assert st.vertices / st.samples > 4  # long paths
 
 
 def test_render_with_mesh_light(rt):
@@ -273,10 +285,42 @@ def test_render_with_mesh_light(rt):
     so = O.build_scene(spec)
     O.set_math(so, portable=True)
     sg = rt.HostScene.from_spec(spec)
-    rgb, st = sg.render(40, 40, 8, seed=2, chunk_spp=4)
     want, stats = O.render(so, 40, 40, 8, seed=2, chunk_spp=4)
-    _assert_images_equal(rgb, want)
+    for how in MODES:
+        rgb, st = sg.render(40, 40, 8, seed=2, chunk_spp=4, **how)
+        _assert_images_equal(rgb, want)
     assert rgb.mean() > 0.001
+
+
+def test_render_scene_too_large_for_lds(rt):
+    """A scene with a few hundred triangles takes the general traversal (per-lane tree
+    walk, geometry from HBM) and by default the wavefront loop; the fused kernel must
+    give the same image with it."""
+    O = Oracle()
+    spec = _random_scene_spec(5)
+    so = O.build_scene(spec)
+    O.set_math(so, portable=True)
+    sg = rt.HostScene.from_spec(spec)
+    want, stats = O.render(so, 40, 32, 6, seed=4, chunk_spp=3)
+    rgb, st = sg.render(40, 32, 6, seed=4, chunk_spp=3)
+    assert st.mode == rt.MODE_WAVEFRONT
+    _assert_images_equal(rgb, want)
+    assert st.rays == stats[1] and st.vertices == stats[3]
+    for how in MODES:
+        rgb, st = sg.render(40, 32, 6, seed=4, chunk_spp=3, **how)
+        _assert_images_equal(rgb, want)
+        assert st.rays == stats[1] and st.vertices == stats[3]
+
+
+def test_fused_and_wavefront_agree_at_many_samples(scenes):
+    """The two loops share no scheduling code; 10^8 rays through both must give the same
+    bits (the checker is too slow for this size)."""
+    O, so, sg = scenes
+    a, sa = sg.render(256, 256, 256, seed=21, mode=2)
+    sg.render(256, 256, 256, seed=22, mode=2)  # overwrite every buffer the library keeps
+    b, sb = sg.render(256, 256, 256, seed=21, mode=1)
+    _assert_images_equal(a, b)
+    assert sa.rays == sb.rays and sa.vertices == sb.vertices and sa.rays > 5e7
 
 
 def test_host_api_render_and_ppm(rt, scenes, tmp_path):
