@@ -295,6 +295,7 @@ k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats
 struct Emit {
   bool has_shadow, has_ext;
   V3 l;          // shadow ray direction, unit(light point - pos)
+  V3 ln, wn;     // unit(l), unit(w1): the directions traversal normalises again
   V3 light_pos;  // the sampled light point
   V3 weight;     // Le * f * cos * cos'
   float light_pdf;
@@ -321,12 +322,13 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const DeviceScene &sc, const Devi
     V3 Le = xyz(mats[sc.prim_material[lprim]].e_kind);
     e.weight = Le * mat_eval_units(dm, ui, l2, un) * dot(N, l2) * dot(unit(ls.nrm), -l2);
     e.l = l;
+    e.ln = l2;
     e.has_shadow = true;
   }
   if (rng.next() < a.rr) {
     V3 wo;
     if (mat_kind(dm) == 1) {
-      wo = mat_mirror(wi, N);
+      wo = mat_mirror_units(ui, un);
     } else {
       float u1 = rng.next();
       float u2 = rng.next();
@@ -334,7 +336,8 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const DeviceScene &sc, const Devi
     }
     float pdf = mat_pdf(dm);
     V3 w1 = unit(wo);
-    e.beta_next = beta * mat_eval_units(dm, ui, unit(w1), un) * dot(N, w1) / pdf / a.rr;
+    e.wn = unit(w1);
+    e.beta_next = beta * mat_eval_units(dm, ui, e.wn, un) * dot(N, w1) / pdf / a.rr;
     e.w1 = w1;
     e.has_ext = true;
   } else {
@@ -617,6 +620,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     Emit e;
     e.has_shadow = false; e.has_ext = false;
     e.l = mk(1, 1, 1); e.w1 = mk(1, 1, 1);
+    e.ln = unit(e.l); e.wn = e.ln;
     e.light_pos = mk(0, 0, 0); e.weight = mk(0, 0, 0); e.beta_next = mk(0, 0, 0);
     e.light_pdf = 0;
     if (live) {
@@ -624,9 +628,19 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       n_vertices++;
       n_rays += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
     }
-    const V3 ln = unit(e.l), wn = unit(e.w1);
-    const HitRec hs = trace_any<kLds>(sc, lds, e.has_shadow, pos, e.l, ln, ws);
-    const HitRec he = trace_any<kLds>(sc, lds, e.has_ext, pos, e.w1, wn, ws);
+    if (!e.has_shadow) { e.l = mk(1, 1, 1); e.ln = unit(e.l); }
+    if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = unit(e.w1); }
+    const V3 ln = e.ln, wn = e.wn;
+    HitRec hs, he;
+    if constexpr (kLds) {
+      // both rays leave the same point: one pass over the leaves for the two of them
+      const HitPair hp = trace_all2(sc, lds, e.has_shadow, e.has_ext, pos, e.l, ln, e.w1, wn, ws.merge);
+      hs = hp.a;
+      he = hp.b;
+    } else {
+      hs = trace_any<kLds>(sc, lds, e.has_shadow, pos, e.l, ln, ws);
+      he = trace_any<kLds>(sc, lds, e.has_ext, pos, e.w1, wn, ws);
+    }
     if (live) {
       // next-event result: src/Render.cpp:95-107.  A miss fails the distance test
       // like the reference's `testInter.hit` does.

@@ -117,6 +117,12 @@ RTR_DEV V3 mat_mirror(V3 wi, V3 n) {
   V3 nn = unit(n);
   return i - 2.0f * dot(nn, i) * nn;
 }
+// the same from ui = unit(wi), un = unit(n): unit(-wi) is -unit(wi) bit for bit
+// (the length is the same and IEEE division is odd in its numerator)
+RTR_DEV V3 mat_mirror_units(V3 ui, V3 un) {
+  V3 i = -ui;
+  return i - 2.0f * dot(un, i) * un;
+}
 
 struct LightSample {
   V3 pos, nrm;

@@ -693,4 +693,177 @@ RTR_DEV int hit_prim(const DeviceScene &sc, const HitRec &h) {
   return (h.leaf >> 30) ? sc.sph_prim[row] : sc.tri_prim[row];
 }
 
+// ---------------------------------------------------------------------------
+// trace_all for two rays that leave the same point (the shadow ray and the
+// extension ray of one path vertex).
+//
+// Everything that depends on the origin only is formed once (s, s x e1 and the
+// numerator of t for triangles; o - c, its square and c for spheres), and the
+// per-ray arithmetic runs in packed fp32 instructions with ray A in the low half
+// and ray B in the high half: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 round each
+// half exactly like the scalar forms, and issue at the same rate.  The sequence of
+// operations per ray is that of trace_all.
+struct V3x2 {
+  f32x2 x, y, z;
+};
+RTR_DEV f32x2 splat(float v) { return f32x2{v, v}; }
+RTR_DEV V3x2 pair(V3 a, V3 b) { return V3x2{{a.x, b.x}, {a.y, b.y}, {a.z, b.z}}; }
+RTR_DEV V3x2 splat(V3 a) { return V3x2{splat(a.x), splat(a.y), splat(a.z)}; }
+RTR_DEV f32x2 dot(V3x2 a, V3x2 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RTR_DEV V3x2 cross(V3x2 a, V3x2 b) {
+  return V3x2{a.y * b.z - a.z * b.y, a.z * b.x - b.z * a.x, a.x * b.y - a.y * b.x};
+}
+RTR_DEV f32x2 div_corrected_pairs(f32x2 a, f32x2 d, f32x2 y) {
+  const f32x2 nd = -d;
+  f32x2 q = a * y;
+  f32x2 r = __builtin_elementwise_fma(nd, q, a);
+  q = __builtin_elementwise_fma(r, y, q);
+  r = __builtin_elementwise_fma(nd, q, a);
+  return __builtin_elementwise_fma(r, y, q);
+}
+
+struct HitPair {
+  HitRec a, b;
+};
+
+struct BestHit {
+  HitRec h;
+  int node;
+  bool nan_seen;
+  RTR_DEV void init() {
+    h.leaf = -1;
+    h.t = 0; h.b1 = 0; h.b2 = 0;
+    node = -1;
+    nan_seen = false;
+  }
+  // src/BVH.cpp:75-76, folded left to right: replaced unless strictly nearer
+  RTR_DEV void fold(bool hit, float t, float b1, float b2, int leaf, int nd) {
+    const bool is_nan = t != t;
+    nan_seen = nan_seen || (hit && is_nan);
+    const bool take = hit && !is_nan && !(h.leaf >= 0 && h.t < t);
+    h.t = take ? t : h.t;
+    h.b1 = take ? b1 : h.b1;
+    h.b2 = take ? b2 : h.b2;
+    h.leaf = take ? leaf : h.leaf;
+    node = take ? nd : node;
+  }
+};
+
+RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool valid_a, bool valid_b,
+                           V3 o, V3 dir_a, V3 dn_a, V3 dir_b, V3 dn_b, MergeStack &merge) {
+  const unsigned lane = threadIdx.x & 63u;
+  const const_leaf *tab = (const const_leaf *)sc.leaves;
+  const int n_leaves = sc.n_leaves;
+  const V3x2 dir = pair(dir_a, dir_b), dn = pair(dn_a, dn_b);
+  const V3x2 ndir = V3x2{-dir.x, -dir.y, -dir.z};
+  const f32x2 qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
+  const f32x2 qa4 = splat(4.0f) * qa;
+  const bool a_fast = qa.x >= 0.5f && qa.x <= 2.0f && qa.y >= 0.5f && qa.y <= 2.0f;
+  const f32x2 ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
+  BestHit ba, bb;
+  ba.init();
+  bb.init();
+  LeafRecord r = load_leaf(tab, 0);
+  for (int k = 0; k < n_leaves; k++) {
+    const LeafRecord nx = load_leaf(tab, k + 1);
+    const int leaf = r.leaf;
+    f32x2 t = splat(0.0f), b1 = t, b2 = t;
+    bool hit_a, hit_b;
+    if (leaf >> 30) {
+      // Sphere::intersect, src/Sphere.cpp:3-39
+      const V3 oc = o - mk(r.a0, r.a1, r.a2);
+      const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+      const float cc = l2 - r.b0;
+      const bool outside = !(l2 < r.b1);
+      const f32x2 b = splat(2.0f) * (splat(oc.x) * dn.x + splat(oc.y) * dn.y + splat(oc.z) * dn.z);
+      const f32x2 delta = b * b - qa4 * splat(cc);
+      const bool reach_a = valid_a && outside && !(delta.x < 0);
+      const bool reach_b = valid_b && outside && !(delta.y < 0);
+      hit_a = false;
+      hit_b = false;
+      if (__ballot(reach_a || reach_b) != 0) {
+        const f32x2 sq = f32x2{sqrtf(delta.x), sqrtf(delta.y)};
+        const f32x2 n1 = (-b + sq) / splat(2.0f), n2 = (-b - sq) / splat(2.0f);
+        f32x2 t1, t2;
+        const bool slow = (reach_a && !(quotient_operand_fast(n1.x) && quotient_operand_fast(n2.x))) ||
+                          (reach_b && !(quotient_operand_fast(n1.y) && quotient_operand_fast(n2.y))) ||
+                          ((reach_a || reach_b) && !a_fast);
+        if (__ballot(slow) == 0) {
+          t1 = div_corrected_pairs(n1, qa, ya);
+          t2 = div_corrected_pairs(n2, qa, ya);
+        } else {
+          t1 = f32x2{n1.x / qa.x, n1.y / qa.y};
+          t2 = f32x2{n2.x / qa.x, n2.y / qa.y};
+        }
+        hit_a = reach_a && !(t1.x < kSphEps);
+        hit_b = reach_b && !(t1.y < kSphEps);
+        t = f32x2{(t2.x < 0) ? t1.x : t2.x, (t2.y < 0) ? t1.y : t2.y};
+      }
+    } else {
+      // Trangle::intersect, src/Trangle.cpp:3-28
+      const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
+      const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
+      const V3 s = o - p0;
+      const V3 s2 = cross(s, e1);
+      const float tnum = dot(s2, e2);
+      const V3x2 s1 = cross(dn, splat(e2));
+      const f32x2 se = dot(s1, splat(e1));
+      const f32x2 inv = f32x2{1 / se.x, 1 / se.y};
+      t = inv * splat(tnum);
+      b1 = inv * dot(s1, splat(s));
+      b2 = inv * dot(splat(s2), dn);
+      const f32x2 w = splat(1.0f) - b1 - b2;
+      const f32x2 facing = dot(ndir, splat(n));
+      hit_a = !(facing.x < 0) &&
+              !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
+      hit_b = !(facing.y < 0) &&
+              !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
+    }
+    ba.fold(hit_a, t.x, b1.x, b2.x, leaf, r.node);
+    bb.fold(hit_b, t.y, b1.y, b2.y, leaf, r.node);
+    r = nx;
+  }
+  // both winners' boxes, leaf to root: Bound3::intersect, src/Bound3.cpp:3-22
+  const bool fast = sc.fast_planes != 0 && fast_ray(o, dn_a) && fast_ray(o, dn_b);
+  const V3 inv_a = mk(1.0f / dn_a.x, 1.0f / dn_a.y, 1.0f / dn_a.z);
+  const V3 inv_b = mk(1.0f / dn_b.x, 1.0f / dn_b.y, 1.0f / dn_b.z);
+  bool ok_a = true, ok_b = true;
+  int na = ba.node, nb = bb.node;
+  while (na >= 0 || nb >= 0) {
+    // a finished chain re-tests the root: harmless, and keeps the loop body straight
+    const int ia = na >= 0 ? na : 0, ib = nb >= 0 ? nb : 0;
+    const float4 lo_a = lds.nodes[2 * ia], hi_a = lds.nodes[2 * ia + 1];
+    const float4 lo_b = lds.nodes[2 * ib], hi_b = lds.nodes[2 * ib + 1];
+    bool pa, pb;
+    if (fast) {
+      pa = slab_fast(lo_a, hi_a, o, dn_a, inv_a);
+      pb = slab_fast(lo_b, hi_b, o, dn_b, inv_b);
+    } else {
+      pa = slab(lo_a, hi_a, o, dn_a);
+      pb = slab(lo_b, hi_b, o, dn_b);
+    }
+    ok_a = ok_a && (pa || na < 0);
+    ok_b = ok_b && (pb || nb < 0);
+    na = na >= 0 ? lds.parent[ia] : -1;
+    nb = nb >= 0 ? lds.parent[ib] : -1;
+  }
+  HitPair out{ba.h, bb.h};
+  unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
+  unsigned long long need_b = __ballot(valid_b && (bb.nan_seen || !ok_b));
+  if (need_a | need_b) {
+    LdsGeom g{lds.nodes, lds.tris, lds.sphs};
+    while (need_a) {
+      int l = __ffsll((long long)need_a) - 1;
+      if ((int)lane == l) out.a = trace_tree(g, o, dir_a, dn_a, merge);
+      need_a &= need_a - 1;
+    }
+    while (need_b) {
+      int l = __ffsll((long long)need_b) - 1;
+      if ((int)lane == l) out.b = trace_tree(g, o, dir_b, dn_b, merge);
+      need_b &= need_b - 1;
+    }
+  }
+  return out;
+}
+
 } // namespace rtr
