@@ -246,6 +246,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
   std::vector<float4> nodes;
   std::vector<int32_t> parent, leaf_nodes;
+  bool nested_boxes = true;
   bool fast_planes = true;  // precondition of the division-free box test (rtr_trace.hpp)
   if (d->n_nodes > 0) {
     const int n = d->n_nodes;
@@ -314,6 +315,13 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
         parent[i + 1] = i;
         parent[i + 1 + size[i + 1]] = i;
       }
+    }
+    // does every box contain its children's boxes, plane by plane?
+    for (int i = 1; i < n; i++) {
+      const float4 &cl = nodes[2 * (size_t)i], &ch = nodes[2 * (size_t)i + 1];
+      const float4 &pl = nodes[2 * (size_t)parent[i]], &ph = nodes[2 * (size_t)parent[i] + 1];
+      if (!(pl.x <= cl.x && pl.y <= cl.y && pl.z <= cl.z && ph.x >= ch.x && ph.y >= ch.y && ph.z >= ch.z))
+        nested_boxes = false;
     }
   }
 
@@ -449,6 +457,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.leaves = s->leaves.ptr;
   s->ds.parent = s->parent.ptr;
   s->ds.n_leaves = (int32_t)leaf_nodes.size();
+  s->ds.nested_boxes = nested_boxes ? 1 : 0;
   s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs;
   s->dl.light = s->lights.ptr;
   s->dl.light_tris = s->light_tris.ptr;

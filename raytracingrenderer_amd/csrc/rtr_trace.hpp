@@ -45,6 +45,7 @@ struct DeviceScene {
   const float4 *leaves;
   const int32_t *parent;
   int32_t n_leaves;
+  int32_t nested_boxes;  // 1: every node's box contains its children's boxes, plane by plane
 };
 
 // Where traversal reads geometry from.  GlobalGeom gathers from HBM through the
@@ -649,11 +650,18 @@ RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid,
     best_node = take ? r.node : best_node;
     r = nx;
   }
-  // the winner's boxes, leaf to root: Bound3::intersect, src/Bound3.cpp:3-22
+  // The winner's boxes, leaf to root: Bound3::intersect, src/Bound3.cpp:3-22.
+  // When boxes are nested (a parent's planes enclose its children's, checked at
+  // scene creation) and all quotients are finite, the leaf's own box decides: with
+  // lo_P <= lo_C and hi_P >= hi_C, every step of the test is monotonic (rounded
+  // subtraction, rounded division by the same d, min, max), so per axis
+  // near_P <= near_C and far_P >= far_C, and  max near_C <= min far_C  implies the
+  // same for the parent, all the way to the root.
   const bool fast = sc.fast_planes != 0 && fast_ray(o, dn);
+  const bool leaf_only = fast && sc.nested_boxes != 0;
   const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
   bool ok = true;
-  for (int node = best_node; node >= 0; node = lds.parent[node]) {
+  for (int node = best_node; node >= 0; node = leaf_only ? -1 : lds.parent[node]) {
     const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
     bool pass;
     if (fast) pass = slab_fast(lo, hi, o, dn, inv);
@@ -823,8 +831,9 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     bb.fold(hit_b, t.y, b1.y, b2.y, leaf, r.node);
     r = nx;
   }
-  // both winners' boxes, leaf to root: Bound3::intersect, src/Bound3.cpp:3-22
+  // both winners' boxes: the leaf's own box, or leaf to root (see trace_all)
   const bool fast = sc.fast_planes != 0 && fast_ray(o, dn_a) && fast_ray(o, dn_b);
+  const bool leaf_only = fast && sc.nested_boxes != 0;
   const V3 inv_a = mk(1.0f / dn_a.x, 1.0f / dn_a.y, 1.0f / dn_a.z);
   const V3 inv_b = mk(1.0f / dn_b.x, 1.0f / dn_b.y, 1.0f / dn_b.z);
   bool ok_a = true, ok_b = true;
@@ -844,8 +853,8 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     }
     ok_a = ok_a && (pa || na < 0);
     ok_b = ok_b && (pb || nb < 0);
-    na = na >= 0 ? lds.parent[ia] : -1;
-    nb = nb >= 0 ? lds.parent[ib] : -1;
+    na = (na >= 0 && !leaf_only) ? lds.parent[ia] : -1;
+    nb = (nb >= 0 && !leaf_only) ? lds.parent[ib] : -1;
   }
   HitPair out{ba.h, bb.h};
   unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
