@@ -80,7 +80,9 @@ struct rtr_scene {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second half of the path pool runs here, overlapping the first
   DevBuf<float4> nodes, tris, sphs, lights, leaves;
-  DevBuf<int32_t> parent;
+  DevBuf<int32_t> parent, node_info;
+  DevBuf<float4> light_le;
+  int n_light_tris = 0;
   DevBuf<int32_t> tri_prim, sph_prim, prim_kind_row, prim_material, light_tris;
   DevBuf<float> tri_area;
   DevBuf<DeviceMaterial> mats;
@@ -373,8 +375,25 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     mats[m].ks_rough = make_float4(d->mat_ks[0][m], d->mat_ks[1][m], d->mat_ks[2][m], d->mat_roughness[m]);
   }
 
+  // per leaf node: prim id | material << 16 | emissive << 30 (small scenes, see hit_info)
+  std::vector<int32_t> node_info(d->n_nodes > 0 ? d->n_nodes : 0, 0);
+  bool info_fits = d->n_prims <= 0xffff && d->n_materials <= 0x3fff;
+  if (info_fits) {
+    for (int i = 0; i < d->n_nodes; i++) {
+      int32_t leaf;
+      memcpy(&leaf, &nodes[2 * (size_t)i + 1].w, 4);
+      if (leaf < 0) continue;
+      int row = leaf & 0x3fffffff;
+      int prim = (leaf >> 30) ? sph_prim[row] : tri_prim[row];
+      int m = prim_material[prim];
+      uint32_t tag;
+      memcpy(&tag, &mats[m].e_kind.w, 4);
+      node_info[i] = prim | (m << 16) | (((tag >> 8) & 1) << 30);
+    }
+  }
+
   // ---- lights ----
-  std::vector<float4> lights(d->n_lights);
+  std::vector<float4> lights(d->n_lights), light_le(d->n_lights, make_float4(0, 0, 0, 0));
   std::vector<int32_t> light_tris;
   float total_area = 0;
   for (int l = 0; l < d->n_lights; l++) {
@@ -382,10 +401,13 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     rec.x = d->light_area[l];
     total_area += d->light_area[l];  // fp32 running sum, src/Scene.cpp:17-20
     int32_t kind = d->light_kind[l], z = 0, w = 0;
+    int32_t le_prim = -1;  // the primitive whose material gives the light's emission
     if (kind == RTR_PRIM_SPHERE) {
       z = d->light_prim[l];
       if (z < 0 || z >= d->n_prims || d->prim_kind[z] != RTR_PRIM_SPHERE)
         return fail(RTR_ERR_INVALID, "sphere light does not name a sphere prim");
+      le_prim = z;
+      z = d->prim_index[z];  // the kernels want the sphere's row
     } else if (kind == RTR_PRIM_TRIANGLE) {
       int b = d->light_tri_begin[l], e = d->light_tri_begin[l + 1];
       if (b < 0 || e < b || (e > b && !d->light_tris))
@@ -396,10 +418,15 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
         if (p < 0 || p >= d->n_prims || d->prim_kind[p] != RTR_PRIM_TRIANGLE)
           return fail(RTR_ERR_INVALID, "mesh light lists a non-triangle prim");
         light_tris.push_back(d->prim_index[p]);
+        le_prim = p;  // samples always land on the last leaf (rtr_shade.hpp: sample_object)
       }
       w = (int32_t)light_tris.size();
     } else {
       return fail(RTR_ERR_INVALID, "unknown light_kind");
+    }
+    if (le_prim >= 0) {
+      int m = prim_material[le_prim];
+      light_le[l] = make_float4(d->mat_emission[0][m], d->mat_emission[1][m], d->mat_emission[2][m], 0);
     }
     memcpy(&rec.y, &kind, 4);
     memcpy(&rec.z, &z, 4);
@@ -439,6 +466,8 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   if ((rc = upload(s->prim_material, prim_material))) return bail(rc);
   if ((rc = upload(s->mats, mats))) return bail(rc);
   if ((rc = upload(s->lights, lights))) return bail(rc);
+  if ((rc = upload(s->light_le, light_le))) return bail(rc);
+  if ((rc = upload(s->node_info, node_info))) return bail(rc);
   if ((rc = upload(s->light_tris, light_tris))) return bail(rc);
   if ((rc = upload(s->tri_area, tri_area))) return bail(rc);
   s->n_materials = d->n_materials;
@@ -458,8 +487,11 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.parent = s->parent.ptr;
   s->ds.n_leaves = (int32_t)leaf_nodes.size();
   s->ds.nested_boxes = nested_boxes ? 1 : 0;
-  s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs;
+  s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs &&
+                    info_fits && fits_lds_shade(d->n_materials, d->n_lights, (int)light_tris.size());
+  s->n_light_tris = (int)light_tris.size();
   s->dl.light = s->lights.ptr;
+  s->dl.light_le = s->light_le.ptr;
   s->dl.light_tris = s->light_tris.ptr;
   s->dl.tri_area = s->tri_area.ptr;
   s->dl.n_lights = d->n_lights;
@@ -473,7 +505,7 @@ void rtr_scene_destroy(rtr_scene *s) {
   DeviceGuard guard(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   s->nodes.release(); s->tris.release(); s->sphs.release(); s->lights.release();
-  s->leaves.release(); s->parent.release();
+  s->leaves.release(); s->parent.release(); s->node_info.release(); s->light_le.release();
   s->tri_prim.release(); s->sph_prim.release(); s->prim_kind_row.release();
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();
@@ -816,10 +848,12 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     HIP_TRY(timed(kFused, [&] {
       if (s->lds_geometry)
         hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                           s->mats.ptr, pc, ws.shade_list.ptr, ws.partial.ptr, cnt);
+                           s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, pc,
+                           ws.shade_list.ptr, ws.partial.ptr, cnt);
       else
         hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                           s->mats.ptr, pc, ws.shade_list.ptr, ws.partial.ptr, cnt);
+                           s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, pc,
+                           ws.shade_list.ptr, ws.partial.ptr, cnt);
     }));
     fused_launches = 1;
     iters = 1;

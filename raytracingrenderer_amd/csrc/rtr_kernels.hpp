@@ -303,14 +303,14 @@ struct Emit {
   V3 beta_next;  // path weight after the bounce (zero if the path stops here)
 };
 
-RTR_DEV void shade_vertex(const RenderArgs &a, const DeviceScene &sc, const DeviceLights &L,
-                          const DeviceMaterial *__restrict__ mats, V3 pos, V3 N, V3 wi, V3 beta,
+template <class Tab>
+RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi, V3 beta,
                           uint32_t mat, uint32_t gpix, uint32_t k, uint32_t depth, Emit &e) {
-  DeviceMaterial dm = mats[mat];
+  DeviceMaterial dm = T.mat(mat);
   const V3 ui = unit(wi), un = unit(N);  // shared by the two evaluations below
   VertexStream rng(a.seed, gpix, k, depth);
   LightSample ls;
-  sample_light(sc, L, rng, ls);
+  sample_light(T, rng, ls);
   e.has_shadow = false;
   e.has_ext = false;
   e.light_pos = ls.pos;
@@ -318,8 +318,7 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const DeviceScene &sc, const Devi
   if (ls.pdf > 0) {
     V3 l = unit(ls.pos - pos);
     V3 l2 = unit(l);
-    int lprim = (ls.leaf >> 30) ? sc.sph_prim[ls.leaf & 0x3fffffff] : sc.tri_prim[ls.leaf];
-    V3 Le = xyz(mats[sc.prim_material[lprim]].e_kind);
+    V3 Le = xyz(T.light_le(ls.light));
     e.weight = Le * mat_eval_units(dm, ui, l2, un) * dot(N, l2) * dot(unit(ls.nrm), -l2);
     e.l = l;
     e.ln = l2;
@@ -475,7 +474,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   bool has_shadow = false, has_ext = false;
   if (live) {
     Emit e;
-    shade_vertex(a, sc, L, mats, pos, N, wi, beta, mat, gpix, k, depth, e);
+    shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
     has_shadow = e.has_shadow;
     has_ext = e.has_ext;
     if (has_shadow) {
@@ -562,53 +561,104 @@ RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const Hit
   }
 }
 
+// Per-lane state of the current work unit lives in LDS (one column per lane, so
+// accesses never conflict): it is touched once per sample, not once per vertex, and
+// the registers it would take decide how many waves fit on a SIMD.
+struct UnitState {
+  float fpos[3][kBlock], fN[3][kBlock], fwi[3][kBlock], acc[3][kBlock];
+  uint32_t fmat[kBlock], lp[kBlock], chunk[kBlock], k_end[kBlock];
+  uint32_t u_lo[kBlock], u_hi[kBlock];
+};
+
+// prim id, material and emissive flag of a hit
 template <bool kLds>
-__global__ void __launch_bounds__(kBlock)
+RTR_DEV void hit_info(const DeviceScene &sc, const DeviceMaterial *__restrict__ mats,
+                      const LdsShade &lsh, const HitRec &h, int node, int &prim, int &mat,
+                      bool &emissive) {
+  if (kLds) {
+    int info = lsh.node_info[node];
+    prim = info & 0xffff;
+    mat = (info >> 16) & 0x3fff;
+    emissive = (info >> 30) & 1;
+  } else {
+    prim = hit_prim(sc, h);
+    mat = sc.prim_material[prim];
+    emissive = mat_emissive(mats[mat]);
+  }
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
+               const int32_t *__restrict__ node_info, int n_materials, int n_light_tris,
                PixelCache pc, const uint32_t *__restrict__ shade_list, float4 *__restrict__ partial,
                Counters *__restrict__ fc) {
   __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
+  __shared__ LdsShade lsh;
+  __shared__ UnitState us;
+  const int tid = threadIdx.x;
   if (kLds) {
-    stage_scene(sc, lds, threadIdx.x, kBlock);
+    stage_scene(sc, lds, tid, kBlock);
+    for (int i = tid; i < n_materials; i += kBlock) lsh.mats[i] = mats[i];
+    for (int i = tid; i < L.n_lights; i += kBlock) { lsh.light[i] = L.light[i]; lsh.light_le[i] = L.light_le[i]; }
+    for (int i = tid; i < n_light_tris; i += kBlock) lsh.light_tris[i] = L.light_tris[i];
+    for (int i = tid; i < sc.n_tris; i += kBlock) lsh.tri_area[i] = L.tri_area[i];
+    for (int i = tid; i < sc.n_nodes; i += kBlock) lsh.node_info[i] = node_info[i];
     __syncthreads();
   }
-  typename WaveLds<kLds>::type &ws = wsh[threadIdx.x >> 6];
+  typename WaveLds<kLds>::type &ws = wsh[tid >> 6];
   const unsigned long long n_lanes = (unsigned long long)gridDim.x * kBlock;
-  unsigned long long u = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;  // next unit of this lane
-
-  // the unit: pixel, its first vertex (the same for all its samples), sample range, sum
-  V3 fpos = mk(0, 0, 0), fN = fpos, fwi = fpos, acc = fpos;
-  uint32_t fmat = 0, gpix = 0, lp = 0, chunk = 0, k = 0, k_end = 0;
+  {
+    const unsigned long long u0 = (unsigned long long)blockIdx.x * kBlock + tid;  // next unit of this lane
+    us.u_lo[tid] = (uint32_t)u0;
+    us.u_hi[tid] = (uint32_t)(u0 >> 32);
+    us.k_end[tid] = 0;
+  }
+  uint32_t gpix = 0, k = 0;
   bool has_unit = false;
   // the path
-  V3 pos = fpos, N = fpos, wi = fpos, beta = fpos, Lp = fpos;
+  V3 pos = mk(0, 0, 0), N = pos, wi = pos, beta = pos, Lp = pos;
   uint32_t mat = 0, depth = 0;
   bool live = false;
   uint32_t n_vertices = 0, n_rays = 0;
 
   for (;;) {
     if (!live) {
-      if (has_unit && k >= k_end) {
-        partial[(size_t)chunk * a.n_pix + lp] = pack(acc, 0.0f);
+      if (has_unit && k >= us.k_end[tid]) {
+        const V3 acc = mk(us.acc[0][tid], us.acc[1][tid], us.acc[2][tid]);
+        partial[(size_t)us.chunk[tid] * a.n_pix + us.lp[tid]] = pack(acc, 0.0f);
         has_unit = false;
       }
-      if (!has_unit && u < a.n_units) {
-        const uint32_t entry = (uint32_t)(u % a.n_shade);
-        chunk = (uint32_t)(u / a.n_shade);
-        u += n_lanes;
-        lp = shade_list[entry];
-        const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
-        fpos = xyz(pm); fmat = wbits(pm);
-        fN = xyz(pn);
-        fwi = xyz(pw); gpix = wbits(pw);
-        k = chunk * (uint32_t)a.chunk_spp;
-        k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
-        acc = mk(0, 0, 0);
-        has_unit = true;
+      if (!has_unit) {
+        unsigned long long u = ((unsigned long long)us.u_hi[tid] << 32) | us.u_lo[tid];
+        if (u < a.n_units) {
+          const uint32_t entry = (uint32_t)(u % a.n_shade);
+          const uint32_t chunk = (uint32_t)(u / a.n_shade);
+          u += n_lanes;
+          us.u_lo[tid] = (uint32_t)u;
+          us.u_hi[tid] = (uint32_t)(u >> 32);
+          const uint32_t lp = shade_list[entry];
+          const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
+          us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
+          us.fmat[tid] = wbits(pm);
+          us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
+          us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
+          gpix = wbits(pw);
+          us.lp[tid] = lp;
+          us.chunk[tid] = chunk;
+          k = chunk * (uint32_t)a.chunk_spp;
+          us.k_end[tid] = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+          us.acc[0][tid] = 0; us.acc[1][tid] = 0; us.acc[2][tid] = 0;
+          has_unit = true;
+        }
       }
       if (has_unit) {
-        pos = fpos; N = fN; wi = fwi; mat = fmat;
+        // new sample: every sample of a pixel starts at the same first vertex
+        pos = mk(us.fpos[0][tid], us.fpos[1][tid], us.fpos[2][tid]);
+        N = mk(us.fN[0][tid], us.fN[1][tid], us.fN[2][tid]);
+        wi = mk(us.fwi[0][tid], us.fwi[1][tid], us.fwi[2][tid]);
+        mat = us.fmat[tid];
         beta = mk(1, 1, 1);
         Lp = mk(0, 0, 0);
         depth = 0;
@@ -619,12 +669,11 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
 
     Emit e;
     e.has_shadow = false; e.has_ext = false;
-    e.l = mk(1, 1, 1); e.w1 = mk(1, 1, 1);
-    e.ln = unit(e.l); e.wn = e.ln;
     e.light_pos = mk(0, 0, 0); e.weight = mk(0, 0, 0); e.beta_next = mk(0, 0, 0);
     e.light_pdf = 0;
     if (live) {
-      shade_vertex(a, sc, L, mats, pos, N, wi, beta, mat, gpix, k, depth, e);
+      if (kLds) shade_vertex(a, LdsTables{lds, lsh, L.n_lights, L.total_area}, pos, N, wi, beta, mat, gpix, k, depth, e);
+      else shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
       n_vertices++;
       n_rays += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
     }
@@ -632,11 +681,13 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = unit(e.w1); }
     const V3 ln = e.ln, wn = e.wn;
     HitRec hs, he;
+    int node_e = -1;
     if constexpr (kLds) {
       // both rays leave the same point: one pass over the leaves for the two of them
       const HitPair hp = trace_all2(sc, lds, e.has_shadow, e.has_ext, pos, e.l, ln, e.w1, wn, ws.merge);
       hs = hp.a;
       he = hp.b;
+      node_e = hp.node_b;
     } else {
       hs = trace_any<kLds>(sc, lds, e.has_shadow, pos, e.l, ln, ws);
       he = trace_any<kLds>(sc, lds, e.has_ext, pos, e.w1, wn, ws);
@@ -656,8 +707,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       // extension result: src/Render.cpp:117-125
       bool cont = false;
       if (e.has_ext && he.leaf >= 0) {
-        int m2 = sc.prim_material[hit_prim(sc, he)];
-        if (!mat_emissive(mats[m2]) && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
+        int prim2, m2;
+        bool emissive;
+        hit_info<kLds>(sc, mats, lsh, he, node_e, prim2, m2, emissive);
+        if (!emissive && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
           V3 hp, hn;
           hit_point_any<kLds>(sc, lds, he, pos, wn, hp, hn);
           beta = e.beta_next;
@@ -670,7 +723,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         }
       }
       if (!cont) {
-        acc = acc + Lp;  // color = color + pathTracing(...), src/Render.cpp:659
+        // color = color + pathTracing(...), src/Render.cpp:659
+        us.acc[0][tid] = us.acc[0][tid] + Lp.x;
+        us.acc[1][tid] = us.acc[1][tid] + Lp.y;
+        us.acc[2][tid] = us.acc[2][tid] + Lp.z;
         k++;
         live = false;
       }
@@ -749,7 +805,7 @@ k_sample_light(DeviceScene sc, DeviceLights L, const float *__restrict__ u, int 
   if (i >= n) return;
   ArrayStream rng{u + (size_t)stride * i, 0u, (uint32_t)stride};
   LightSample ls;
-  sample_light(sc, L, rng, ls);
+  sample_light(GlobalTables{sc, L, nullptr}, rng, ls);
   pos[3 * i] = ls.pos.x; pos[3 * i + 1] = ls.pos.y; pos[3 * i + 2] = ls.pos.z;
   nrm[3 * i] = ls.nrm.x; nrm[3 * i + 1] = ls.nrm.y; nrm[3 * i + 2] = ls.nrm.z;
   pdf[i] = ls.pdf;

@@ -17,12 +17,57 @@ struct DeviceMaterial {  // 3 x float4
 };
 
 struct DeviceLights {
-  const float4 *light;        // per light: { area, bits(kind), bits(prim or tri_begin), bits(tri_end) }
+  const float4 *light;        // per light: { area, bits(kind), bits(sphere row or tri_begin), bits(tri_end) }
+  const float4 *light_le;     // per light: emission of the primitive its samples land on
   const int32_t *light_tris;  // triangle ROWS (not prim ids) in mesh leaf order
   const float *tri_area;      // per triangle row
   int32_t n_lights;
   float total_area;           // sum in Scene::lights order, fp32 (src/Scene.cpp:17-20)
 };
+
+// Where shading reads its tables from: HBM through the caches, or copies a
+// workgroup staged in LDS (scenes small enough; a dependent chain of global loads
+// costs a path vertex more than all its arithmetic when few waves share a SIMD).
+constexpr int kLdsMats = 32, kLdsLights = 16, kLdsLightTris = kLdsTris;
+struct LdsShade {
+  DeviceMaterial mats[kLdsMats];
+  float4 light[kLdsLights], light_le[kLdsLights];
+  int32_t light_tris[kLdsLightTris];
+  float tri_area[kLdsTris];
+  int32_t node_info[kLdsNodes];  // leaf nodes: prim id | material << 16 | emissive << 30
+};
+struct GlobalTables {
+  const DeviceScene &sc;
+  const DeviceLights &L;
+  const DeviceMaterial *mats;
+  RTR_DEV DeviceMaterial mat(int m) const { return mats[m]; }
+  RTR_DEV float4 light(int l) const { return L.light[l]; }
+  RTR_DEV float4 light_le(int l) const { return L.light_le[l]; }
+  RTR_DEV int light_tri(int k) const { return L.light_tris[k]; }
+  RTR_DEV float tri_area(int row) const { return L.tri_area[row]; }
+  RTR_DEV float4 tri(int row, int k) const { return sc.tris[3 * row + k]; }
+  RTR_DEV float4 sph(int row) const { return sc.sphs[row]; }
+  RTR_DEV int n_lights() const { return L.n_lights; }
+  RTR_DEV float total_area() const { return L.total_area; }
+};
+struct LdsTables {
+  const LdsScene &g;
+  const LdsShade &s;
+  int32_t nl;
+  float area;
+  RTR_DEV DeviceMaterial mat(int m) const { return s.mats[m]; }
+  RTR_DEV float4 light(int l) const { return s.light[l]; }
+  RTR_DEV float4 light_le(int l) const { return s.light_le[l]; }
+  RTR_DEV int light_tri(int k) const { return s.light_tris[k]; }
+  RTR_DEV float tri_area(int row) const { return s.tri_area[row]; }
+  RTR_DEV float4 tri(int row, int k) const { return g.tris[3 * row + k]; }
+  RTR_DEV float4 sph(int row) const { return g.sphs[row]; }
+  RTR_DEV int n_lights() const { return nl; }
+  RTR_DEV float total_area() const { return area; }
+};
+__host__ __device__ inline bool fits_lds_shade(int n_materials, int n_lights, int n_light_tris) {
+  return n_materials <= kLdsMats && n_lights <= kLdsLights && n_light_tris <= kLdsLightTris;
+}
 
 RTR_DEV int mat_kind(const DeviceMaterial &m) { return (int)(wbits(m.e_kind) & 0xff); }
 RTR_DEV bool mat_emissive(const DeviceMaterial &m) { return (wbits(m.e_kind) >> 8) & 1; }
@@ -127,19 +172,20 @@ RTR_DEV V3 mat_mirror_units(V3 ui, V3 un) {
 struct LightSample {
   V3 pos, nrm;
   float pdf;
-  int32_t leaf;  // (kind << 30) | row of the sampled primitive, -1 if none
+  int32_t leaf;   // (kind << 30) | row of the sampled primitive, -1 if none
+  int32_t light;  // index of the light the sample was taken from
 };
 
 // Sphere::sample, src/Sphere.cpp:41-48 (theta is drawn before phi)
-template <class Rng>
-RTR_DEV void sample_sphere(const DeviceScene &sc, int row, float area, Rng &rng, LightSample &ls) {
+template <class Tab, class Rng>
+RTR_DEV void sample_sphere(const Tab &T, int row, float area, Rng &rng, LightSample &ls) {
   float theta = (float)(2.0 * kPi * (double)rng.next());
   float phi = (float)(kPi * (double)rng.next());
   float st, ct, sp, cp;
   sincos_fixed(theta, st, ct);
   sincos_fixed(phi, sp, cp);
   V3 d = mk(cp, sp * ct, sp * st);
-  float4 q = sc.sphs[row];
+  float4 q = T.sph(row);
   ls.pos = xyz(q) + q.w * d;
   ls.nrm = d;
   ls.leaf = (1 << 30) | row;
@@ -147,12 +193,11 @@ RTR_DEV void sample_sphere(const DeviceScene &sc, int row, float area, Rng &rng,
 }
 
 // Trangle::sample, src/Trangle.cpp:42-49
-template <class Rng>
-RTR_DEV void sample_triangle(const DeviceScene &sc, int row, float area, Rng &rng,
-                             LightSample &ls) {
+template <class Tab, class Rng>
+RTR_DEV void sample_triangle(const Tab &T, int row, float area, Rng &rng, LightSample &ls) {
   float b1 = rng.next();
   float b2 = (float)((double)rng.next() * (1.0 - (double)b1));
-  float4 q0 = sc.tris[3 * row], q1 = sc.tris[3 * row + 1], q2 = sc.tris[3 * row + 2];
+  float4 q0 = T.tri(row, 0), q1 = T.tri(row, 1), q2 = T.tri(row, 2);
   ls.pos = (1 - b1 - b2) * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2);
   ls.nrm = mk(q0.w, q1.w, q2.w);
   ls.leaf = row;
@@ -163,14 +208,13 @@ RTR_DEV void sample_triangle(const DeviceScene &sc, int row, float area, Rng &rn
 // (include/Trangle.h:103-108) whose walk (src/BVH.cpp:82-95) re-samples at every
 // leaf from the first selected one on, so the LAST leaf decides; the draws the
 // earlier leaves would have consumed are skipped by advancing the counter.
-template <class Rng>
-RTR_DEV void sample_object(const DeviceScene &sc, const DeviceLights &L, int l, Rng &rng,
-                           LightSample &ls) {
-  float4 rec = L.light[l];
+template <class Tab, class Rng>
+RTR_DEV void sample_object(const Tab &T, int l, Rng &rng, LightSample &ls) {
+  float4 rec = T.light(l);
   float area = rec.x;
+  ls.light = l;
   if (__float_as_int(rec.y) == 1) {
-    int prim = __float_as_int(rec.z);
-    sample_sphere(sc, sc.prim_kind_row[prim] & 0x3fffffff, area, rng, ls);
+    sample_sphere(T, __float_as_int(rec.z), area, rng, ls);
     return;
   }
   ls.pdf = -1.0f;
@@ -178,14 +222,14 @@ RTR_DEV void sample_object(const DeviceScene &sc, const DeviceLights &L, int l, 
   int b = __float_as_int(rec.z), e = __float_as_int(rec.w);
   int first = -1;
   for (int k = b; k < e; k++) {
-    rest -= L.tri_area[L.light_tris[k]];
+    rest -= T.tri_area(T.light_tri(k));
     if ((double)rest < 1e-3) { first = k; break; }
   }
   if (first >= 0) {
     rng.dim += 2u * (uint32_t)(e - 1 - first);  // draws of the leaves that get overwritten
-    int row = L.light_tris[e - 1];
-    float a = L.tri_area[row];
-    sample_triangle(sc, row, a, rng, ls);
+    int row = T.light_tri(e - 1);
+    float a = T.tri_area(row);
+    sample_triangle(T, row, a, rng, ls);
     ls.pdf *= a;
   }
   ls.pdf /= area;
@@ -193,23 +237,24 @@ RTR_DEV void sample_object(const DeviceScene &sc, const DeviceLights &L, int l, 
 
 // Scene::samplingLight, src/Scene.cpp:16-35 (caller presets pdf = -1,
 // src/Render.cpp:91).
-template <class Rng>
-RTR_DEV void sample_light(const DeviceScene &sc, const DeviceLights &L, Rng &rng,
-                          LightSample &ls) {
+template <class Tab, class Rng>
+RTR_DEV void sample_light(const Tab &T, Rng &rng, LightSample &ls) {
   ls.pdf = -1.0f;
   ls.leaf = -1;
+  ls.light = 0;
   ls.pos = mk(0, 0, 0);
   ls.nrm = mk(0, 0, 0);
-  float pick = rng.next() * L.total_area;
-  for (int i = 0; i < L.n_lights; i++) {
+  const int n_lights = T.n_lights();
+  float pick = rng.next() * T.total_area();
+  for (int i = 0; i < n_lights; i++) {
     if ((double)pick < 1e-3) {
-      sample_object(sc, L, i, rng, ls);
+      sample_object(T, i, rng, ls);
       break;
     } else {
-      pick -= L.light[i].x;
+      pick -= T.light(i).x;
     }
   }
-  if (ls.pdf < 0 && L.n_lights > 0) sample_object(sc, L, L.n_lights - 1, rng, ls);
+  if (ls.pdf < 0 && n_lights > 0) sample_object(T, n_lights - 1, rng, ls);
 }
 
 } // namespace rtr

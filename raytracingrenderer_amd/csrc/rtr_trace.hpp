@@ -730,8 +730,18 @@ RTR_DEV f32x2 div_corrected_pairs(f32x2 a, f32x2 d, f32x2 y) {
   return __builtin_elementwise_fma(r, y, q);
 }
 
+// node index of a leaf payload in a staged scene (only used after the rare literal
+// tree evaluation, which reports the leaf but not where it sits)
+RTR_DEV int node_of_leaf(const LdsScene &lds, int n_nodes, int leaf) {
+  if (leaf < 0) return -1;
+  for (int i = 0; i < n_nodes; i++)
+    if (__float_as_int(lds.nodes[2 * i + 1].w) == leaf) return i;
+  return -1;
+}
+
 struct HitPair {
   HitRec a, b;
+  int node_a, node_b;  // the leaves' node indices (-1 for a miss)
 };
 
 struct BestHit {
@@ -856,19 +866,25 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     na = (na >= 0 && !leaf_only) ? lds.parent[ia] : -1;
     nb = (nb >= 0 && !leaf_only) ? lds.parent[ib] : -1;
   }
-  HitPair out{ba.h, bb.h};
+  HitPair out{ba.h, bb.h, ba.node, bb.node};
   unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
   unsigned long long need_b = __ballot(valid_b && (bb.nan_seen || !ok_b));
   if (need_a | need_b) {
     LdsGeom g{lds.nodes, lds.tris, lds.sphs};
     while (need_a) {
       int l = __ffsll((long long)need_a) - 1;
-      if ((int)lane == l) out.a = trace_tree(g, o, dir_a, dn_a, merge);
+      if ((int)lane == l) {
+        out.a = trace_tree(g, o, dir_a, dn_a, merge);
+        out.node_a = node_of_leaf(lds, sc.n_nodes, out.a.leaf);
+      }
       need_a &= need_a - 1;
     }
     while (need_b) {
       int l = __ffsll((long long)need_b) - 1;
-      if ((int)lane == l) out.b = trace_tree(g, o, dir_b, dn_b, merge);
+      if ((int)lane == l) {
+        out.b = trace_tree(g, o, dir_b, dn_b, merge);
+        out.node_b = node_of_leaf(lds, sc.n_nodes, out.b.leaf);
+      }
       need_b &= need_b - 1;
     }
   }
