@@ -844,6 +844,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       s->fused_grid = per_cu * cus;
     }
     unsigned grid = (unsigned)s->fused_grid;
+    if (grid > 65535u) grid = 65535u;  // the kernel counts lanes in 24 bits
     if ((uint64_t)grid * kBlock > n_units) grid = (unsigned)((n_units + kBlock - 1) / kBlock);
     HIP_TRY(timed(kFused, [&] {
       if (s->lds_geometry)

@@ -566,9 +566,10 @@ RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const Hit
 // the registers it would take decide how many waves fit on a SIMD.
 struct UnitState {
   float fpos[3][kBlock], fN[3][kBlock], fwi[3][kBlock], acc[3][kBlock];
-  uint32_t fmat[kBlock], lp[kBlock], chunk[kBlock], k_end[kBlock];
-  uint32_t u_lo[kBlock], u_hi[kBlock];
+  uint32_t fmat[kBlock], out[kBlock], k_end[kBlock];  // out: index of the unit's partial sum
+  uint32_t next[kBlock];                              // next unit of this lane, kNoUnit: none
 };
+constexpr uint32_t kNoUnit = 0xffffffffu;
 
 // prim id, material and emissive flag of a hit
 template <bool kLds>
@@ -587,8 +588,10 @@ RTR_DEV void hit_info(const DeviceScene &sc, const DeviceMaterial *__restrict__ 
   }
 }
 
+// Four waves per SIMD (128 registers): with few waves the kernel waits on its own
+// instruction latencies; the handful of spills this costs is cheaper.
 template <bool kLds>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kLds ? 4 : 1, kLds ? 4 : 8)))
 k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
                const int32_t *__restrict__ node_info, int n_materials, int n_light_tris,
                PixelCache pc, const uint32_t *__restrict__ shade_list, float4 *__restrict__ partial,
@@ -608,11 +611,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     __syncthreads();
   }
   typename WaveLds<kLds>::type &ws = wsh[tid >> 6];
-  const unsigned long long n_lanes = (unsigned long long)gridDim.x * kBlock;
+  const uint32_t n_lanes = gridDim.x * kBlock;  // the host keeps the grid below 2^24 lanes
   {
-    const unsigned long long u0 = (unsigned long long)blockIdx.x * kBlock + tid;  // next unit of this lane
-    us.u_lo[tid] = (uint32_t)u0;
-    us.u_hi[tid] = (uint32_t)(u0 >> 32);
+    const uint32_t u0 = blockIdx.x * kBlock + tid;
+    us.next[tid] = u0 < a.n_units ? u0 : kNoUnit;
     us.k_end[tid] = 0;
   }
   uint32_t gpix = 0, k = 0;
@@ -627,17 +629,16 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if (!live) {
       if (has_unit && k >= us.k_end[tid]) {
         const V3 acc = mk(us.acc[0][tid], us.acc[1][tid], us.acc[2][tid]);
-        partial[(size_t)us.chunk[tid] * a.n_pix + us.lp[tid]] = pack(acc, 0.0f);
+        partial[us.out[tid]] = pack(acc, 0.0f);
         has_unit = false;
       }
       if (!has_unit) {
-        unsigned long long u = ((unsigned long long)us.u_hi[tid] << 32) | us.u_lo[tid];
-        if (u < a.n_units) {
-          const uint32_t entry = (uint32_t)(u % a.n_shade);
-          const uint32_t chunk = (uint32_t)(u / a.n_shade);
-          u += n_lanes;
-          us.u_lo[tid] = (uint32_t)u;
-          us.u_hi[tid] = (uint32_t)(u >> 32);
+        const uint32_t u = us.next[tid];
+        if (u != kNoUnit) {
+          const uint32_t entry = u % a.n_shade;
+          const uint32_t chunk = u / a.n_shade;
+          // n_units is below 2^32 - 16 and n_lanes below 2^24: the sum cannot wrap
+          us.next[tid] = (a.n_units - u > n_lanes) ? u + n_lanes : kNoUnit;
           const uint32_t lp = shade_list[entry];
           const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
           us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
@@ -645,8 +646,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
           us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
           us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
           gpix = wbits(pw);
-          us.lp[tid] = lp;
-          us.chunk[tid] = chunk;
+          us.out[tid] = chunk * (uint32_t)a.n_pix + lp;  // below 2^32: checked by the host
           k = chunk * (uint32_t)a.chunk_spp;
           us.k_end[tid] = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
           us.acc[0][tid] = 0; us.acc[1][tid] = 0; us.acc[2][tid] = 0;
@@ -683,6 +683,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     HitRec hs, he;
     int node_e = -1;
     if constexpr (kLds) {
+
       // both rays leave the same point: one pass over the leaves for the two of them
       const HitPair hp = trace_all2(sc, lds, e.has_shadow, e.has_ext, pos, e.l, ln, e.w1, wn, ws.merge);
       hs = hp.a;
