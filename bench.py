@@ -50,7 +50,7 @@ def cpu_baseline(W, H):
     if have_ref():
         R = Ref()
         sr = R.default_scene()
-        spp = 16
+        spp = 64  # about 15 s on 16 host cores
         # the reference prints progress with std::cout: keep fd 1 clean for the JSON line
         sys.stdout.flush()
         saved = os.dup(1)

@@ -115,3 +115,23 @@ def same_bits(a, b):
     b = np.ascontiguousarray(b, f32)
     eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
     return eq
+
+
+def heightfield_spec(n, seed=1234):
+    """The default scene plus one mesh of 2*n*n triangles: a jittered height field inside
+    the box (n = 708 gives the ~1 M-triangle case, a nested tree about 20 levels deep)."""
+    from _oracle import default_scene_spec
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(40, 472, n + 1)
+    zs = np.linspace(-472, -40, n + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = 60 + 25 * np.sin(X / 37.0) * np.cos(Z / 29.0) + rng.uniform(-1.5, 1.5, X.shape)
+    verts = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(f32)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a = (i * (n + 1) + j).reshape(-1)
+    b, c = a + 1, a + (n + 1)
+    d = c + 1
+    idx = np.stack([a, b, c, b, d, c], 1).reshape(-1).astype(np.uint32)  # faces up
+    spec = default_scene_spec()
+    spec["objects"] = spec["objects"] + [("mesh", "white", verts, idx)]
+    return spec

@@ -96,6 +96,26 @@ def test_closest_hit_random_scene_deep_tree(rt):
     _assert_hits_equal(sg.intersect(org, d), so.intersect(org, d))
 
 
+def test_million_triangle_mesh(rt):
+    """Default scene + a 708 x 708 jittered height field (1 002 528 triangles, 2 M nodes):
+    closest hits of 400 000 rays and a small image, bit for bit; the general traversal
+    (per-lane walk, geometry gathered from HBM) and both sampling loops."""
+    O = Oracle()
+    spec = _rays.heightfield_spec(708)
+    so = O.build_scene(spec)
+    O.set_math(so, portable=True)
+    sg = rt.HostScene.from_spec(spec)
+    org, d = _rays.interior_rays(400000, seed=5)
+    want = so.intersect(org, d)
+    _assert_hits_equal(sg.intersect(org, d), want)
+    assert (want[0] >= 19).mean() > 0.1  # tens of thousands of rays end on the mesh
+    img, stats = O.render(so, 32, 32, 4, seed=9, chunk_spp=2)
+    for how in (dict(mode=1), dict(mode=2)):
+        rgb, st = sg.render(32, 32, 4, seed=9, chunk_spp=2, **how)
+        _assert_images_equal(rgb, img)
+        assert st.rays == stats[1] and st.vertices == stats[3]
+
+
 def test_closest_hit_degenerate_triangles_nan_distance(rt):
     """Zero-area and edge-on triangles give inf/NaN distances that still count as
     hits in the reference; the merge order then decides.  Must match bit for bit."""
