@@ -220,6 +220,8 @@ RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
 // 0 or of magnitude in [2^-20, 2^20].  Then every a = plane - o is 0 or at least
 // 2^-44, quotients lie in [2^-45, 2^41] and the residuals stay normal numbers.
 // All values are finite, so plain min/max equal the reference's swap-and-select.
+// (A zero quotient may come out as +0 where IEEE gives -0; the two compare equal in
+// every min, max and <= of the test, so its boolean is unaffected.)
 RTR_DEV float div_corrected(float a, float d, float y) {
   float q = a * y;
   float r = __builtin_fmaf(-d, q, a);
@@ -563,8 +565,10 @@ constexpr float kTriEps = ceil_to_float(-1e-5);   // src/Trangle.cpp:17
 constexpr float kSphEps = ceil_to_float(1e-3);    // src/Sphere.cpp:29
 
 RTR_DEV bool quotient_operand_fast(float n) {
+  // [2^-40, 2^40]; zero is left to the IEEE division: the corrections lose the sign
+  // of a zero quotient, and the root is returned as the hit distance
   float m = fabsf(n);
-  return m == 0.0f || (m >= 9.094947017729282e-13f && m <= 1099511627776.0f);  // 0 or [2^-40, 2^40]
+  return m >= 9.094947017729282e-13f && m <= 1099511627776.0f;
 }
 
 RTR_DEV LeafRecord load_leaf(const const_leaf *tab, int k) {
@@ -585,7 +589,7 @@ RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid,
   const float qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
   const float qa4 = 4 * qa;
   // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
-  // when qa is in [0.5, 2] and |n| is zero or in [2^-40, 2^40]
+  // when qa is in [0.5, 2] and |n| is in [2^-40, 2^40]
   const bool a_fast = qa >= 0.5f && qa <= 2.0f;
   const float ya = 1.0f / qa;
   HitRec best;
