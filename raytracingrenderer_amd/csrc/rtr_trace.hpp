@@ -409,98 +409,6 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
   return best;
 }
 
-// The same for scenes of at most 64 nodes: the wave scans the nodes together.
-//
-// In such a scene a ray's line crosses most boxes anyway (the reference's box
-// test has no t >= 0 clause; on the Cornell box a ray visits 23 of the 37 nodes
-// on average and the slowest lane of a wave 30), so per-lane walking buys little
-// and costs per-lane node loads, leaf/kind selects and divergent bookkeeping.
-// Here the node index k is wave-uniform: node data comes through the scalar
-// cache into SGPRs, the leaf branch is a scalar branch, and each lane only keeps
-// `resume`, the index at which it becomes active again (a lane that misses node k
-// sleeps until skip[k], i.e. through k's subtree -- exactly the nodes the
-// reference's recursion would not visit for that ray).  When no lane hits an
-// inner node the whole wave jumps to skip[k]: lanes already asleep there wake up
-// at or after skip[k], because they sleep since an ancestor of k.
-struct NodeRecord {  // one node as laid out in HBM (two float4)
-  float lox, loy, loz;
-  int skip;
-  float hix, hiy, hiz;
-  int leaf;
-};
-typedef const NodeRecord __attribute__((address_space(4))) const_node;
-
-template <class Geom>
-RTR_DEV HitRec trace_wave_scan(const Geom &g, const float4 *nodes_global, int n_nodes,
-                               bool fast_planes, bool valid, V3 o, V3 dir, V3 dn, WaveShared &ws) {
-  const unsigned lane = threadIdx.x & 63u;
-  ws.w.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
-  ws.w.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
-  ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);
-  ws.w.key[lane] = ~0ull;
-  if (lane == 0) ws.nan_mask = 0;
-  const bool fast = fast_planes && fast_ray(o, dn);
-  const bool any_slow = __ballot(valid && !fast) != 0;
-  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
-  const const_node *nodes = (const const_node *)nodes_global;  // uniform index -> scalar loads
-  unsigned head0 = 0, tail0 = 0, head1 = 0, tail1 = 0;  // wave-uniform ring cursors
-  int resume = valid ? 0 : n_nodes;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (int k = 0; k < n_nodes;) {
-    const float4 lo = make_float4(nodes[k].lox, nodes[k].loy, nodes[k].loz, 0.0f);
-    const float4 hi = make_float4(nodes[k].hix, nodes[k].hiy, nodes[k].hiz, 0.0f);
-    const int skip = nodes[k].skip;
-    const int leaf = nodes[k].leaf;
-    const bool active = k >= resume;
-    bool pass = slab_fast(lo, hi, o, dn, inv);
-    if (any_slow && !fast) pass = slab(lo, hi, o, dn);
-    pass = pass && active;
-    if (active && !pass) resume = skip;
-    const unsigned long long m = __ballot(pass);
-    if (leaf < 0) {
-      k = m ? k + 1 : skip;
-      continue;
-    }
-    if (m) {
-      const uint32_t entry = lane | ((uint32_t)k << 6);
-      const unsigned rank = (unsigned)__popcll(m & below), cnt = (unsigned)__popcll(m);
-      if (leaf >> 30) {
-        if (pass) ws.w.ring[1][(tail1 + rank) & 127u] = entry;
-        tail1 += cnt;
-        if (tail1 - head1 >= 64u) {
-          test_round<1>(g, ws, head1, 64u);
-          head1 += 64u;
-        }
-      } else {
-        if (pass) ws.w.ring[0][(tail0 + rank) & 127u] = entry;
-        tail0 += cnt;
-        if (tail0 - head0 >= 64u) {
-          test_round<0>(g, ws, head0, 64u);
-          head0 += 64u;
-        }
-      }
-    }
-    k = k + 1;
-  }
-  if (tail0 != head0) test_round<0>(g, ws, head0, tail0 - head0);
-  if (tail1 != head1) test_round<1>(g, ws, head1, tail1 - head1);
-
-  HitRec best;
-  best.leaf = -1;
-  best.t = 0; best.b1 = 0; best.b2 = 0;
-  if (ws.w.key[lane] != ~0ull) {
-    float4 h = ws.w.hit[lane];
-    best.t = h.x; best.b1 = h.y; best.b2 = h.z; best.leaf = __float_as_int(h.w);
-  }
-  unsigned long long need = ws.nan_mask;
-  while (need) {
-    int l = __ffsll((long long)need) - 1;
-    if ((int)lane == l) best = trace_tree(g, o, dir, dn, ws.merge);
-    need &= need - 1;
-  }
-  return best;
-}
-
 // Geometry staged in LDS by a whole workgroup (kernels call this before tracing,
 // every thread of the block, then __syncthreads()).
 constexpr int kLdsNodes = 64, kLdsTris = 48, kLdsSphs = 32;
@@ -510,9 +418,6 @@ struct LdsScene {
   float4 sphs[kLdsSphs];
   int32_t parent[kLdsNodes];
 };
-RTR_DEV bool fits_lds(const DeviceScene &sc) {
-  return sc.n_nodes <= kLdsNodes && sc.n_tris <= kLdsTris && sc.n_sphs <= kLdsSphs;
-}
 RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthreads) {
   for (int k = tid; k < 2 * sc.n_nodes; k += nthreads) s.nodes[k] = sc.nodes[k];
   for (int k = tid; k < 3 * sc.n_tris; k += nthreads) s.tris[k] = sc.tris[k];
