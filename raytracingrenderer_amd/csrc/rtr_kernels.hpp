@@ -62,6 +62,7 @@ struct Counters {
   unsigned int n_shade;  // pixels that need sampling (k_classify)
   unsigned int pad;
   unsigned long long vertices, rays;  // totals of the fused sampling kernel
+  unsigned long long next_unit;       // its cursor: first unit no wave has reserved yet
 };
 
 // The render loop uses no global atomics.  Every k_logic workgroup owns one
@@ -539,11 +540,14 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
 // of their paths, so there is nothing to sort or compact, and no path state,
 // ray queue or hit record goes through HBM.
 //
-// Units are dealt statically: with T lanes in the grid, lane g takes units
-// g, g + T, g + 2T, ...; unit u is (chunk u / n_shade, pixel-list entry u % n_shade),
-// so the lanes of a wave start on neighbouring pixels.  The image is the same as
-// the wavefront loop's, bit for bit: a unit's samples are summed in order by
-// whichever lane owns it.
+// Units are handed out on demand: a wave reserves 64 consecutive units with one
+// atomic add on a global cursor and deals them to its lanes as they run out of
+// work (ranks from a ballot, no memory traffic), so all lanes of the grid finish
+// within one unit of each other -- with a static split the slowest lane of every
+// wave, and the slowest wave, held the rest up for several per cent of the run.
+// Unit u is (chunk u / n_shade, pixel-list entry u % n_shade).  Which lane takes a
+// unit does not matter: a unit's samples are summed in order by whoever owns it, so
+// the image is the same as the wavefront loop's, bit for bit.
 template <bool kLds>
 RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const HitRec &h, V3 o, V3 dn,
                            V3 &pos, V3 &nrm) {
@@ -567,9 +571,7 @@ RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const Hit
 struct UnitState {
   float fpos[3][kBlock], fN[3][kBlock], fwi[3][kBlock], acc[3][kBlock];
   uint32_t fmat[kBlock], out[kBlock], k_end[kBlock];  // out: index of the unit's partial sum
-  uint32_t next[kBlock];                              // next unit of this lane, kNoUnit: none
 };
-constexpr uint32_t kNoUnit = 0xffffffffu;
 
 // prim id, material and emissive flag of a hit
 template <bool kLds>
@@ -611,12 +613,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     __syncthreads();
   }
   typename WaveLds<kLds>::type &ws = wsh[tid >> 6];
-  const uint32_t n_lanes = gridDim.x * kBlock;  // the host keeps the grid below 2^24 lanes
-  {
-    const uint32_t u0 = blockIdx.x * kBlock + tid;
-    us.next[tid] = u0 < a.n_units ? u0 : kNoUnit;
-    us.k_end[tid] = 0;
-  }
+  us.k_end[tid] = 0;
+  // the wave's reservation: units [res_base, res_base + res_left) are not dealt yet
+  uint32_t res_base = 0, res_left = 0;
+  bool drained = false;  // the global cursor has passed the last unit
   uint32_t gpix = 0, k = 0;
   bool has_unit = false;
   // the path
@@ -632,27 +632,45 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         partial[us.out[tid]] = pack(acc, 0.0f);
         has_unit = false;
       }
-      if (!has_unit) {
-        const uint32_t u = us.next[tid];
-        if (u != kNoUnit) {
-          const uint32_t entry = u % a.n_shade;
-          const uint32_t chunk = u / a.n_shade;
-          // n_units is below 2^32 - 16 and n_lanes below 2^24: the sum cannot wrap
-          us.next[tid] = (a.n_units - u > n_lanes) ? u + n_lanes : kNoUnit;
-          const uint32_t lp = shade_list[entry];
-          const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
-          us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
-          us.fmat[tid] = wbits(pm);
-          us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
-          us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
-          gpix = wbits(pw);
-          us.out[tid] = chunk * (uint32_t)a.n_pix + lp;  // below 2^32: checked by the host
-          k = chunk * (uint32_t)a.chunk_spp;
-          us.k_end[tid] = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
-          us.acc[0][tid] = 0; us.acc[1][tid] = 0; us.acc[2][tid] = 0;
-          has_unit = true;
+    }
+    // deal units to the lanes that have none (wave-uniform control flow)
+    for (unsigned long long want = __ballot(!live && !has_unit); want != 0;
+         want = __ballot(!live && !has_unit)) {
+      if (res_left == 0) {
+        if (drained) break;
+        unsigned long long base = 0;
+        if (lane_id() == 0) base = atomicAdd(&fc->next_unit, 64ull);
+        base = __shfl(base, 0);
+        if (base >= a.n_units) {
+          drained = true;
+          break;
         }
+        res_base = (uint32_t)base;
+        res_left = min(64u, a.n_units - res_base);
       }
+      const uint32_t rank = (uint32_t)__popcll(want & lanes_below());
+      if (!live && !has_unit && rank < res_left) {
+        const uint32_t u = res_base + rank;
+        const uint32_t entry = u % a.n_shade;
+        const uint32_t chunk = u / a.n_shade;
+        const uint32_t lp = shade_list[entry];
+        const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
+        us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
+        us.fmat[tid] = wbits(pm);
+        us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
+        us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
+        gpix = wbits(pw);
+        us.out[tid] = chunk * (uint32_t)a.n_pix + lp;  // below 2^32: checked by the host
+        k = chunk * (uint32_t)a.chunk_spp;
+        us.k_end[tid] = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+        us.acc[0][tid] = 0; us.acc[1][tid] = 0; us.acc[2][tid] = 0;
+        has_unit = true;
+      }
+      const uint32_t dealt = min((uint32_t)__popcll(want), res_left);
+      res_base += dealt;
+      res_left -= dealt;
+    }
+    if (!live) {
       if (has_unit) {
         // new sample: every sample of a pixel starts at the same first vertex
         pos = mk(us.fpos[0][tid], us.fpos[1][tid], us.fpos[2][tid]);
