@@ -7,7 +7,8 @@ full render of that image; the scene is already resident in HBM when the timed
 region starts and the framebuffer stays in HBM (a torch tensor).
 
 N>1 (launched by torch.distributed.run, one process per GPU): the same image is
-cut into interleaved 8-column tiles, rank r renders tiles t with t % N == r with
+cut into interleaved column tiles (8 columns or fewer, so that every rank gets the same
+number of columns), rank r renders tiles t with t % N == r with
 no traffic between GPUs, and one gather (RCCL) brings the framebuffer to rank 0,
 which restores column order.  Total work is fixed, so "scaling" is "strong".
 
@@ -117,7 +118,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, spp = args.width, args.height, args.spp
-    tile = 8
+    # column tiles are dealt round-robin to the ranks: the widest tile (up to 8 columns)
+    # that gives every rank the same number of columns, else 8
+    tile = next((t for t in (8, 7, 6, 5, 4, 3, 2, 1) if W % t == 0 and (W // t) % world == 0), 8)
     scene = rt.default_scene()
     scene.set_device(local_rank)
     scene.device_scene()  # upload now: the scene is resident before the timed region

@@ -691,7 +691,9 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   a.seed = prm->seed;
   a.max_depth = prm->max_depth > 0 ? prm->max_depth : 0;
   a.rr = prm->rr_prob > 0 ? prm->rr_prob : 0.6f;
-  a.chunk_spp = prm->chunk_spp > 0 ? prm->chunk_spp : (prm->spp + 63) / 64;
+  // default: 128 partial sums per pixel -- units small enough that the last one a lane
+  // works on is a small share of its run, also when the image is split over 8 GPUs
+  a.chunk_spp = prm->chunk_spp > 0 ? prm->chunk_spp : (prm->spp + 127) / 128;
   if (a.chunk_spp > a.spp) a.chunk_spp = a.spp;
   a.n_chunks = (a.spp + a.chunk_spp - 1) / a.chunk_spp;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -803,12 +805,18 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
                        s->mats.ptr, cs, ws.pix_dir.ptr, ws.pix_hit.ptr, pc, ws.shade_list.ptr, cnt,
                        ws.partial.ptr);
   }));
-  HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  harvest();
-  const uint64_t n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
-  a.n_shade = ws.host_counters->n_shade;
-  a.n_units = (uint32_t)n_units;
+  // The wavefront loop sizes its pool and its unit schedule from the number of
+  // pixels that need sampling; the fused kernel reads that counter on the device, so
+  // nothing waits between classification and sampling.
+  uint64_t n_units = (uint64_t)a.n_pix * a.n_chunks;  // fused mode: an upper bound
+  if (!fused) {
+    HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    harvest();
+    n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
+    a.n_shade = ws.host_counters->n_shade;
+    a.n_units = (uint32_t)n_units;
+  }
   if (n_units > 0 && !fused) {
     // static unit schedule (see k_logic): `lanes` pixel-list entries in flight,
     // `per_pixel` slots sharing the chunks of one entry
@@ -844,7 +852,6 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       s->fused_grid = per_cu * cus;
     }
     unsigned grid = (unsigned)s->fused_grid;
-    if (grid > 65535u) grid = 65535u;  // the kernel counts lanes in 24 bits
     if ((uint64_t)grid * kBlock > n_units) grid = (unsigned)((n_units + kBlock - 1) / kBlock);
     HIP_TRY(timed(kFused, [&] {
       if (s->lds_geometry)
@@ -858,10 +865,6 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     }));
     fused_launches = 1;
     iters = 1;
-    HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    total_rays = ws.host_counters->rays;
-    total_vertices = ws.host_counters->vertices;
   } else if (n_units > 0) {
     const int batch = 16;
     // The pool is driven as two halves on two streams (streams = 2).  Path logic is
@@ -914,8 +917,13 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a,
                        ws.partial.ptr, d_rgb);
   }));
+  if (fused) HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   harvest();
+  if (fused) {
+    total_rays = ws.host_counters->rays;
+    total_vertices = ws.host_counters->vertices;
+  }
   for (Span &sp : free_spans) {
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);

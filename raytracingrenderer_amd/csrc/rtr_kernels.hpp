@@ -590,10 +590,15 @@ RTR_DEV void hit_info(const DeviceScene &sc, const DeviceMaterial *__restrict__ 
   }
 }
 
-// Four waves per SIMD (128 registers): with few waves the kernel waits on its own
-// instruction latencies; the handful of spills this costs is cheaper.
+// Four waves per SIMD (128 registers): with three the kernel waits on its own
+// instruction latencies (-8 %); the few dozen spilled registers this costs are
+// cheaper.  RTR_FUSED_WAVES=3 builds the spill-free variant.
+#ifndef RTR_FUSED_WAVES
+#define RTR_FUSED_WAVES 4
+#endif
 template <bool kLds>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kLds ? 4 : 1, kLds ? 4 : 8)))
+__global__ void __launch_bounds__(kBlock)
+    __attribute__((amdgpu_waves_per_eu(kLds ? RTR_FUSED_WAVES : 1, kLds ? RTR_FUSED_WAVES : 8)))
 k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
                const int32_t *__restrict__ node_info, int n_materials, int n_light_tris,
                PixelCache pc, const uint32_t *__restrict__ shade_list, float4 *__restrict__ partial,
@@ -614,6 +619,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
   }
   typename WaveLds<kLds>::type &ws = wsh[tid >> 6];
   us.k_end[tid] = 0;
+  // the number of pixels that need sampling comes straight from the classification
+  // kernel's counter: the host does not wait for it between the two launches
+  const uint32_t n_shade = __atomic_load_n(&fc->n_shade, __ATOMIC_RELAXED);
+  const uint32_t n_units = n_shade * (uint32_t)a.n_chunks;  // fits: the host bounds pixels * chunks
   // the wave's reservation: units [res_base, res_base + res_left) are not dealt yet
   uint32_t res_base = 0, res_left = 0;
   bool drained = false;  // the global cursor has passed the last unit
@@ -641,18 +650,18 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         unsigned long long base = 0;
         if (lane_id() == 0) base = atomicAdd(&fc->next_unit, 64ull);
         base = __shfl(base, 0);
-        if (base >= a.n_units) {
+        if (base >= n_units) {
           drained = true;
           break;
         }
         res_base = (uint32_t)base;
-        res_left = min(64u, a.n_units - res_base);
+        res_left = min(64u, n_units - res_base);
       }
       const uint32_t rank = (uint32_t)__popcll(want & lanes_below());
       if (!live && !has_unit && rank < res_left) {
         const uint32_t u = res_base + rank;
-        const uint32_t entry = u % a.n_shade;
-        const uint32_t chunk = u / a.n_shade;
+        const uint32_t entry = u % n_shade;
+        const uint32_t chunk = u / n_shade;
         const uint32_t lp = shade_list[entry];
         const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
         us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;

@@ -15,4 +15,4 @@ for world in (1, 2, 4, 8):
         for _ in range(3):
             st = sg.render_device(784, 784, 1024, local.data_ptr(), part_index=rank, part_count=world, tile_cols=8, profile=True)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 3 * 1e3)
-    print("world %d: per-rank ms %s  fused kernel ms %.2f  ideal %.2f" % (world, ["%.2f" % t for t in ts], st.ms_fused, 148.2 / world), flush=True)
+    print("world %d: per-rank ms %s  last call: total %.2f fused %.2f trace %.3f other %.3f" % (world, ["%.2f" % t for t in ts], st.ms_total, st.ms_fused, st.ms_trace, st.ms_other), flush=True)
