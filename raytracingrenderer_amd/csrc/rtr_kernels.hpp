@@ -1,17 +1,20 @@
-// The wavefront path tracer's kernels (gfx950, wave64).
+// The path tracer's kernels (gfx950, wave64).
 //
-// One render = ray generation -> primary trace -> classify, then a loop of
-//   pt_logic  (consume last iteration's hits, Russian roulette result, path
-//              regeneration, light sampling, BSDF sampling, ray emission with
-//              64-wide ballot compaction into the ray queue)
-//   pt_trace  (closest hit for every queued ray)
-// and a final resolve.  Path state lives in HBM as float4 structure-of-arrays
-// indexed by slot; a slot keeps one path and moves on to the next sample of its
-// work unit when the path ends, so lanes stay busy while samples remain.
+// One render = ray generation -> primary trace -> classify, the sampling loop, and
+// a final resolve.  The sampling loop exists twice, with the same image bit for bit:
 //
-// A work unit is (pixel, chunk of consecutive samples).  A slot sums its unit's
-// samples in order in registers/state and writes ONE partial sum per unit, so
-// the image needs no atomics and is bit-reproducible: it does not depend on the
+//   fused      k_render_fused: one persistent kernel, one path per lane, path state
+//              in registers, both rays of a vertex traced by the lane itself; for
+//              scenes small enough to be staged in LDS.
+//   wavefront  a loop of k_logic (consume last iteration's hits, Russian roulette
+//              result, path regeneration, light sampling, BSDF sampling, ray emission
+//              with 64-wide ballot compaction into the ray queue) and k_trace_queue
+//              (closest hit for every queued ray); path state lives in HBM as float4
+//              structure-of-arrays indexed by slot.
+//
+// A work unit is (pixel, chunk of consecutive samples).  A lane or slot sums its
+// unit's samples in order and writes ONE partial sum per unit, so the image needs
+// no atomics and is bit-reproducible: it does not depend on the loop variant, the
 // pool size, the scheduling order or how columns are split across GPUs.
 #pragma once
 #include "rtr_shade.hpp"
@@ -65,7 +68,7 @@ struct Counters {
   unsigned long long next_unit;       // its cursor: first unit no wave has reserved yet
 };
 
-// The render loop uses no global atomics.  Every k_logic workgroup owns one
+// The wavefront loop uses no global atomics.  Every k_logic workgroup owns one
 // record and one fixed segment of the ray queue; the host adds the records up.
 // (Per-wave, and then per-workgroup, atomics on shared counters used to be the
 // largest single cost of the path-logic kernel.)
@@ -83,7 +86,7 @@ struct RenderArgs {
   int32_t max_depth;
   float rr;
   int32_t chunk_spp, n_chunks, pool;
-  uint32_t n_shade, n_units;  // known after k_classify
+  uint32_t n_shade, n_units;  // wavefront loop only: read back after k_classify
   int32_t first;              // 1 on the first iteration: no slot has a unit yet
   uint32_t unit_lanes, unit_per_pixel;  // static unit schedule, see k_logic
 };
