@@ -2,7 +2,7 @@
 """Benchmark of the path-tracing hot path on MI355X.
 
 Workload (N=1): the reference's default Cornell-box scene (src/main.cpp:7-84),
-path tracing, 784x784 at 1024 spp -- BASELINE.json configs[1].  One "step" is one
+path tracing, 784x784 at 1024 spp (the configuration the headline metric is quoted on).  One "step" is one
 full render of that image; the scene is already resident in HBM when the timed
 region starts and the framebuffer stays in HBM (a torch tensor).
 

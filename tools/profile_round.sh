@@ -1,8 +1,8 @@
 #!/bin/bash
-# Profiles committed under profiles/<round>/: rocprofv3 kernel-trace statistics of the
+# Profiles committed under profiles/<label>/: rocprofv3 kernel-trace statistics of the
 # default bench.py run, and HBM traffic counters of the dominant kernel (two separate
 # counter passes, as the TCC block cannot hold FETCH_SIZE and WRITE_SIZE together).
-# usage (on the GPU box): tools/profile_round.sh r01
+# usage (on the GPU box): tools/profile_round.sh <label>
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${1:-r01}
