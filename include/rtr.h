@@ -193,6 +193,16 @@ int rtr_trace_closest_device(rtr_scene *scene, const float *d_org_xyz, const flo
                              float *d_nrm_xyz, void *stream);
 
 /*
+ * Scene::checkConnectable (include/Scene.h:49-56), the visibility test the
+ * reference's bidirectional integrator builds on: the closest hit along
+ * a -> b, connected[i] = 1 iff something is hit and |distance - |b - a|| < 1e-3
+ * (the ESP argument of the reference is not used by its body).  a_xyz / b_xyz:
+ * count rows of x,y,z in host memory.  Same booleans as the reference.
+ */
+int rtr_check_connectable(rtr_scene *scene, const float *a_xyz, const float *b_xyz, size_t count,
+                          uint8_t *connected);
+
+/*
  * Material::eval / Material::pdf / Material::sample (src/Material.cpp:66-168) on
  * the device, one row per query.  u2: the two uniforms Material::sample would
  * draw, in draw order (alph, theta).  Any output may be NULL.

@@ -976,6 +976,19 @@ void orc_intersect(const orc_scene *s, const float *org3, const float *dir3, int
   }
 }
 
+// include/Scene.h:49-56
+void orc_check_connectable(const orc_scene *s, const float *a3, const float *b3, int64_t n,
+                           uint8_t *connected) {
+  for (int64_t i = 0; i < n; i++) {
+    V3 a = mk(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
+    V3 b = mk(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]);
+    V3 ab = b - a;
+    Hit h = closest(s, a, unit(ab), nullptr);
+    // std::abs(float) against the double literal 1e-3
+    connected[i] = (h.hit && (double)fabsf(h.t - length(ab)) < 1e-3) ? 1 : 0;
+  }
+}
+
 int orc_slab(const float bmin[3], const float bmax[3], const float org[3], const float dir[3]) {
   Box b(mk(bmin[0], bmin[1], bmin[2]), mk(bmax[0], bmax[1], bmax[2]));
   return slab(b, mk(org[0], org[1], org[2]), mk(dir[0], dir[1], dir[2])) ? 1 : 0;

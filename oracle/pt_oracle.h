@@ -84,6 +84,11 @@ void orc_intersect(const orc_scene *s, const float *org3, const float *dir3,
 /* Bound3::intersect on an explicit box, src/Bound3.cpp:3-22 */
 int orc_slab(const float bmin[3], const float bmax[3], const float org[3],
              const float dir[3]);
+/* Scene::checkConnectable, include/Scene.h:49-56: closest hit along a -> b, connected
+ * iff something is hit and |distance - |b - a|| < 1e-3 (the ESP argument is unused there). */
+void orc_check_connectable(const orc_scene *s, const float *a3, const float *b3, int64_t n,
+                           uint8_t *connected);
+
 /* per-query visit counters accumulated by orc_intersect since the last reset:
  * [0]=queries [1]=box tests [2]=triangle tests [3]=sphere tests */
 void orc_counters(uint64_t out[4], int reset);

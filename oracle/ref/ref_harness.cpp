@@ -216,6 +216,12 @@ void ref_intersect(void *h, const float *org3, const float *dir3, int64_t n, int
   }
 }
 
+void ref_check_connectable(void *h, const float *a3, const float *b3, int64_t n, uint8_t *connected) {
+  RefScene *r = (RefScene *)h;
+  for (int64_t i = 0; i < n; i++)
+    connected[i] = r->scene->checkConnectable(v3(a3 + 3 * i), v3(b3 + 3 * i)) ? 1 : 0;
+}
+
 int ref_slab(const float bmin[3], const float bmax[3], const float org[3], const float dir[3]) {
   Bound3 b(v3(bmin), v3(bmax));
   Ray ray(v3(org), v3(dir));

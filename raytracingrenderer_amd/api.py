@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "rtr_last_error", "rtr_device_count", "rtr_scene_create", "rtr_scene_destroy",
     "rtr_trace_closest", "rtr_trace_closest_device", "rtr_material_eval", "rtr_material_sample",
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
-    "rtr_partition_columns",
+    "rtr_partition_columns", "rtr_check_connectable",
 ]
 
 _hip = None
@@ -79,6 +79,7 @@ def hip_lib():
         L.rtr_trace_closest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
+        L.rtr_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.rtr_material_eval.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp, _fp]
         L.rtr_material_sample.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp]
         L.rtr_sample_light.argtypes = [C.c_void_p, _fp, C.c_int32, C.c_size_t, _fp, _fp, _fp, _ip,
@@ -119,6 +120,7 @@ def host_lib():
         L.rtrh_device_scene.restype = C.c_void_p
         L.rtrh_material_id.argtypes = [C.c_void_p, C.c_int]
         L.rtrh_intersect.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
+        L.rtrh_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, C.POINTER(C.c_uint8)]
         L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
                                   C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
         _host = L
@@ -284,6 +286,22 @@ class HostScene:
         _check(hip_lib().rtr_trace_closest(self.device_scene(), _f(org), _f(dirs), n, _i(prim),
                                            _f(t), _f(pos), _f(nrm)), "rtr_trace_closest")
         return prim, t, pos, nrm
+
+    def check_connectable(self, a, b, via_host_api=False):
+        """Scene::checkConnectable for many pairs: uint8 array, 1 where b is reached from a.
+        via_host_api: through the C++ mirror (Scene::checkConnectableBatch) instead of the
+        C ABI call directly."""
+        a = np.ascontiguousarray(a, f32).reshape(-1, 3)
+        b = np.ascontiguousarray(b, f32).reshape(-1, 3)
+        out = np.zeros(len(a), np.uint8)
+        op = out.ctypes.data_as(C.POINTER(C.c_uint8))
+        if via_host_api:
+            if host_lib().rtrh_check_connectable(self.h, _f(a), _f(b), len(a), op) != 0:
+                self._herr("checkConnectable")
+        else:
+            _check(hip_lib().rtr_check_connectable(self.device_scene(), _f(a), _f(b), len(a), op),
+                   "rtr_check_connectable")
+        return out
 
     def material_eval(self, mat, wi, wo, n):
         wi, wo, n = [np.ascontiguousarray(a, f32) for a in (wi, wo, n)]

@@ -657,6 +657,30 @@ int rtr_stream_uniform(rtr_scene *s, uint32_t seed, const uint32_t *pixel, const
   return RTR_OK;
 }
 
+int rtr_check_connectable(rtr_scene *s, const float *a_xyz, const float *b_xyz, size_t count,
+                          uint8_t *connected) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (count == 0) return RTR_OK;
+  if (!a_xyz || !b_xyz || !connected) return fail(RTR_ERR_INVALID, "null array");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->io_f[0].reserve(3 * count));
+  HIP_TRY(s->io_f[1].reserve(3 * count));
+  HIP_TRY(s->io_i[0].reserve((count + 3) / 4));
+  HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, a_xyz, 12 * count, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->io_f[1].ptr, b_xyz, 12 * count, hipMemcpyHostToDevice, s->stream));
+  unsigned char *out = (unsigned char *)s->io_i[0].ptr;
+  if (s->lds_geometry)
+    hipLaunchKernelGGL(k_check_connectable<true>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
+                       s->ds, (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr, count, out);
+  else
+    hipLaunchKernelGGL(k_check_connectable<false>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
+                       s->ds, (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr, count, out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(connected, out, count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
 int rtr_partition_columns(int32_t width, int32_t part_index, int32_t part_count,
                           int32_t tile_cols, int32_t *n_columns, int32_t *columns) {
   if (width < 0 || (part_count > 1 && (part_index < 0 || part_index >= part_count)))

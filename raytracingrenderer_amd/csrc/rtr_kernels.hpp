@@ -154,6 +154,33 @@ k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restri
   if (nrm) { nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z; }
 }
 
+// ---- Scene::checkConnectable, include/Scene.h:49-56 ----
+// Closest hit from a towards b; connected iff something is hit and its distance is
+// within 1e-3 of |b - a| (the reference's ESP argument is not used by its body).
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock)
+k_check_connectable(DeviceScene sc, const float *__restrict__ a3, const float *__restrict__ b3, size_t n,
+                    unsigned char *__restrict__ connected) {
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
+  __shared__ LdsScene lds;
+  if (kLds) {
+    stage_scene(sc, lds, threadIdx.x, kBlock);
+    __syncthreads();
+  }
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  V3 a = mk(0, 0, 0), ab = mk(1, 1, 1);
+  if (valid) {
+    a = mk(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
+    ab = mk(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]) - a;
+  }
+  const V3 d = unit(ab);  // Ray(a, (b - a).normalize())
+  HitRec h = trace_any<kLds>(sc, lds, valid, a, d, unit(d), wsh[threadIdx.x >> 6]);
+  if (!valid) return;
+  // std::abs(float) against the double literal 1e-3
+  connected[i] = (h.leaf >= 0 && (double)fabsf(h.t - length(ab)) < 1e-3) ? 1 : 0;
+}
+
 // ---- traversal of the primary rays (one per pixel, shared by all its samples) ----
 template <bool kLds>
 __global__ void __launch_bounds__(kBlock)

@@ -388,6 +388,17 @@ void Scene::intersectBatch(const float *org_xyz, const float *dir_xyz, size_t n,
             "rtr_trace_closest");
 }
 
+void Scene::checkConnectableBatch(const float *a_xyz, const float *b_xyz, size_t n, uint8_t *connected) {
+  rtr_check(rtr_check_connectable(deviceScene(), a_xyz, b_xyz, n, connected), "rtr_check_connectable");
+}
+
+bool Scene::checkConnectable(Vector3f a, Vector3f b, float) {
+  const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z};
+  uint8_t out = 0;
+  checkConnectableBatch(pa, pb, 1, &out);
+  return out != 0;
+}
+
 Intersection Scene::intersect(const Ray &ray) {
   const float o[3] = {ray.startPos.x, ray.startPos.y, ray.startPos.z};
   const float d[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
@@ -646,6 +657,11 @@ int rtrh_intersect(void *hs, const float *org, const float *dir, int64_t n, int3
                    float *pos, float *nrm) {
   HostScene *h = (HostScene *)hs;
   return guarded([&] { h->scene->intersectBatch(org, dir, (size_t)n, prim, t, pos, nrm); });
+}
+
+int rtrh_check_connectable(void *hs, const float *a, const float *b, int64_t n, uint8_t *connected) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] { h->scene->checkConnectableBatch(a, b, (size_t)n, connected); });
 }
 
 // Render::renderPathTracing; file may be NULL/"" (no PPM).  rgb gets the buffer.

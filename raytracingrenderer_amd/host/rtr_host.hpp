@@ -234,6 +234,9 @@ class Scene {
   // many rays at once: prim ids (-1 = miss) and distances; pos/nrm optional (n*3)
   void intersectBatch(const float *org_xyz, const float *dir_xyz, size_t n, int32_t *prim_id,
                       float *t, float *pos_xyz = nullptr, float *nrm_xyz = nullptr);
+  // include/Scene.h:49-56 (ESP is ignored there, and here), and many pairs at once
+  bool checkConnectable(Vector3f a, Vector3f b, float ESP = 1e-3);
+  void checkConnectableBatch(const float *a_xyz, const float *b_xyz, size_t n, uint8_t *connected);
 
   void setDevice(int index);
   const FlatScene &flatten();  // (re)built after rebuildBVH

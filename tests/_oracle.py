@@ -100,6 +100,8 @@ class _Backend:
         getattr(L, p + "object_area").argtypes = [C.c_void_p, C.c_int]
         getattr(L, p + "object_area").restype = C.c_float
         getattr(L, p + "intersect").argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
+        getattr(L, p + "check_connectable").argtypes = [C.c_void_p, _fp, _fp, C.c_int64,
+                                                        C.POINTER(C.c_uint8)]
         getattr(L, p + "slab").argtypes = [_fp, _fp, _fp, _fp]
         getattr(L, p + "material_eval").argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]
         getattr(L, p + "material_pdf").argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]
@@ -163,6 +165,13 @@ class Scene:
         nrm = np.zeros((n, 3), f32)
         self._fn("intersect")(self.h, _f(org), _f(dirs), n, _i(prim), _f(t), _f(pos), _f(nrm))
         return prim, t, pos, nrm
+
+    def check_connectable(self, a, b):
+        a = np.ascontiguousarray(a, f32).reshape(-1, 3)
+        b = np.ascontiguousarray(b, f32).reshape(-1, 3)
+        out = np.zeros(len(a), np.uint8)
+        self._fn("check_connectable")(self.h, _f(a), _f(b), len(a), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
 
     def material_eval(self, mat, wi, wo, n):
         wi, wo, n = [np.ascontiguousarray(a, f32) for a in (wi, wo, n)]

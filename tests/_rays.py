@@ -135,3 +135,27 @@ def heightfield_spec(n, seed=1234):
     spec = default_scene_spec()
     spec["objects"] = spec["objects"] + [("mesh", "white", verts, idx)]
     return spec
+
+
+def connection_pairs(scene, n, seed):
+    """Point pairs for Scene::checkConnectable: surface points found by tracing random
+    interior rays with `scene` (anything with .intersect), paired up at random -- roughly
+    half of them see each other -- plus pairs that must fail or are degenerate: a point
+    and itself, a point behind a wall, points in mid-air."""
+    rng = np.random.default_rng(seed)
+    org, d = interior_rays(2 * n, seed + 1)
+    prim, t, pos, nrm = scene.intersect(org, d)
+    pts = pos[prim >= 0]
+    # lift the points a little off their surface so that the connecting ray does not start
+    # inside the 1e-5 slack of the triangle it lies on
+    lift = nrm[prim >= 0] * f32(0.05)
+    pts = (pts + lift).astype(f32)
+    k = min(n, len(pts) // 2)
+    a, b = pts[:k].copy(), pts[k:2 * k].copy()
+    # the exact surface points as targets (what a light or camera vertex would be)
+    b[::2] = pos[prim >= 0][k:2 * k][::2]
+    extra_a = np.array([[256, 256, -100], [256, 256, -100], [100, 100, -100], [256, 400, -256],
+                        [10, 10, -10]], f32)
+    extra_b = np.array([[256, 256, -100], [256, 256, -700], [300, 310, -120], [256, 100, -256],
+                        [500, 500, -500]], f32)
+    return np.concatenate([a, extra_a]), np.concatenate([b, extra_b])

@@ -40,11 +40,23 @@ def multi_light_spec():
     return spec
 
 
+def connectable(sr):
+    """Scene::checkConnectable (include/Scene.h:49-56) of the reference on point pairs found
+    with the reference's own closest-hit query."""
+    a, b = _rays.connection_pairs(sr, 8000, 7)
+    got = sr.check_connectable(a, b)
+    np.savez_compressed(os.path.join(HERE, "connect_default.npz"), a=a, b=b, connected=got)
+    print("connectable pairs:", len(a), "connected:", int(got.sum()))
+
+
 def main():
     R = Ref()
     O = Oracle()  # only used to generate primary-ray INPUTS (camera set-up)
     sr = R.default_scene()
     so = O.default_scene()
+    connectable(sr)
+    if "--only-connectable" in sys.argv:
+        return
 
     lo, hi, child, prim = sr.flatten()
     np.savez_compressed(os.path.join(HERE, "bvh_default.npz"), bmin=lo, bmax=hi, child=child,

@@ -103,6 +103,13 @@ def test_path_tracing_golden(osc):
         assert _rays.same_bits(got, g["rgb"][k]).all(), (k, got, g["rgb"][k])
 
 
+def test_check_connectable_golden(osc):
+    O, so = osc
+    g = _load("connect_default.npz")
+    assert np.array_equal(so.check_connectable(g["a"], g["b"]), g["connected"])
+    assert 2000 < g["connected"].sum() < len(g["a"]) - 2000
+
+
 def test_philox_known_answers(osc):
     """Philox4x32-10 known-answer vectors of the Random123 distribution."""
     O, _ = osc
@@ -185,6 +192,15 @@ def test_gpu_material_eval_golden(gsc):
         flipped = (np.sign(got) != np.sign(g["sample_" + m])).all(1)  # dot(wo,n) ~ 0
         assert (err[~flipped] <= 4 * 1.2e-7).all(), (m, err.max())
         assert flipped.mean() < 0.002
+
+
+@pytest.mark.gpu
+def test_gpu_check_connectable_golden(gsc):
+    rt, sg = gsc
+    g = _load("connect_default.npz")
+    assert np.array_equal(sg.check_connectable(g["a"], g["b"]), g["connected"])
+    assert np.array_equal(sg.check_connectable(g["a"][:500], g["b"][:500], via_host_api=True),
+                          g["connected"][:500])
 
 
 @pytest.mark.gpu

@@ -142,6 +142,22 @@ def test_closest_hit_degenerate_triangles_nan_distance(rt):
     _assert_hits_equal(sg.intersect(org, d), want)
 
 
+def test_check_connectable(rt, scenes):
+    """Scene::checkConnectable on the default scene (all-leaves traversal) and on a scene
+    with thousands of primitives (tree walk): same booleans as the checker."""
+    O, so, sg = scenes
+    a, b = _rays.connection_pairs(so, 100000, 11)
+    want = so.check_connectable(a, b)
+    assert np.array_equal(sg.check_connectable(a, b), want)
+    assert 0.2 < want.mean() < 0.8
+    spec = _random_scene_spec(9)
+    so2 = O.build_scene(spec)
+    sg2 = rt.HostScene.from_spec(spec)
+    a, b = _rays.connection_pairs(so2, 50000, 12)
+    assert np.array_equal(sg2.check_connectable(a, b), so2.check_connectable(a, b))
+    assert len(sg.check_connectable(np.zeros((0, 3), f32), np.zeros((0, 3), f32))) == 0
+
+
 def test_empty_and_tiny_batches(scenes):
     O, so, sg = scenes
     p, t, pos, n = sg.intersect(np.zeros((0, 3), f32), np.zeros((0, 3), f32))

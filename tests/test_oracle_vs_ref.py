@@ -100,6 +100,24 @@ def test_closest_hit_random_scene(both):
     assert _rays.same_bits(no, nr)[hit].all()
 
 
+def test_check_connectable(both):
+    """Scene::checkConnectable, include/Scene.h:49-56: same booleans on surface-point pairs
+    (about 40 % connected), degenerate pairs included; also on a random scene."""
+    O, R, so, sr = both
+    a, b = _rays.connection_pairs(sr, 20000, 3)
+    co, cr = so.check_connectable(a, b), sr.check_connectable(a, b)
+    assert np.array_equal(co, cr)
+    assert 0.2 < cr.mean() < 0.8
+    rng = np.random.default_rng(5)
+    spec = default_scene_spec()
+    pts = rng.uniform(0, 512, (600, 3)).astype(f32) * np.array([1, 1, -1], f32)
+    idx = rng.integers(0, 600, 900).astype(np.uint32)
+    spec["objects"] = spec["objects"] + [("mesh", "white", pts, idx)]
+    so2, sr2 = O.build_scene(spec), R.build_scene(spec)
+    a, b = _rays.connection_pairs(sr2, 10000, 4)
+    assert np.array_equal(so2.check_connectable(a, b), sr2.check_connectable(a, b))
+
+
 def _dirs(n, seed):
     rng = np.random.default_rng(seed)
     v = rng.normal(size=(n, 3)).astype(f32)
