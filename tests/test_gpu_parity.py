@@ -359,6 +359,35 @@ def test_fused_and_wavefront_agree_at_many_samples(scenes):
     assert sa.rays == sb.rays and sa.vertices == sb.vertices and sa.rays > 5e7
 
 
+def test_benchmark_size_image_properties(rt, scenes):
+    """The benchmark's own workload, 784 x 784 at 1024 spp (6.3e8 samples, 2e9 rays), which
+    the CPU checker cannot reach: the two sampling loops, which share no scheduling code,
+    must agree in every bit, and so must the image assembled from 8 column partitions."""
+    O, so, sg = scenes
+    W = H = 784
+    spp = 1024
+    full, st = sg.render(W, H, spp, seed=0)
+    assert st.mode == rt.MODE_FUSED and st.samples == W * H * spp
+    assert 3.0 < st.rays / st.samples < 3.5 and 1.9 < st.vertices / st.samples < 2.2
+    sg.render(W, H, 8, seed=5)  # overwrite the library's buffers in between
+    wf, sw = sg.render(W, H, spp, seed=0, mode=rt.MODE_WAVEFRONT)
+    _assert_images_equal(wf, full)
+    assert (sw.rays, sw.vertices) == (st.rays, st.vertices)
+    out = np.zeros_like(full).reshape(W, H, 3)
+    rays = 0
+    for r in range(8):
+        part, sp = sg.render(W, H, spp, seed=0, part_index=r, part_count=8, tile_cols=7)
+        cols = rt.partition_columns(W, r, 8, 7)
+        assert len(cols) == W // 8
+        out[cols] = part.reshape(len(cols), H, 3)
+        rays += sp.rays
+    _assert_images_equal(out.reshape(-1, 3), full)
+    assert rays == st.rays
+    # light pixels are exact, and the picture is what the reference converges to
+    lum = (full * np.array([0.2126, 0.7152, 0.0722], f32)).sum(1)
+    assert 0.15 < lum.mean() < 0.18  # the reference's mean image is (0.224, 0.152, 0.119)
+
+
 def test_host_api_render_and_ppm(rt, scenes, tmp_path):
     """Render::renderPathTracing of the host library: same buffer as the C ABI call,
     and the PPM bytes follow src/Render.cpp:3-21 (header 'height width', gamma 0.6)."""
