@@ -52,6 +52,7 @@ struct Workspace {
   DevBuf<float4> pix_dir, pix_hit, pc_pos, pc_nrm, pc_wi, partial;
   DevBuf<float4> pool[14];
   DevBuf<uint32_t> shade_list, queue;
+  DevBuf<uint2> wave_res;  // wavefront loop: each wave's reserved, not yet dealt units
   DevBuf<int32_t> cols;
   DevBuf<float> rgb;
   DevBuf<Counters> counters;
@@ -64,6 +65,7 @@ struct Workspace {
     partial.release();
     for (auto &b : pool) b.release();
     shade_list.release(); queue.release(); cols.release(); rgb.release(); counters.release();
+    wave_res.release();
     block_counters.release();
     if (host_counters) (void)hipHostFree(host_counters);
     if (host_block_counters) (void)hipHostFree(host_block_counters);
@@ -727,7 +729,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   // upper bound of the pool; the exact size follows from the number of pixels
   // that need sampling (known after k_classify)
   size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 21);
-  size_t pool = pool_target + (size_t)a.n_pix;  // lanes*per_pixel never exceeds this
+  size_t pool = pool_target;
   if (pool > max_units) pool = max_units;
   pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
   if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
@@ -748,6 +750,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (fused) pool = kLogicBlock * kGroup;  // the wavefront buffers are not used
   for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
   HIP_TRY(ws.queue.reserve(2 * pool));  // one segment of kSegment entries per k_logic workgroup
+  HIP_TRY(ws.wave_res.reserve(pool / 64));
   HIP_TRY(ws.counters.reserve(1));
   if (!ws.host_counters) HIP_TRY(hipHostMalloc((void **)&ws.host_counters, sizeof(Counters)));
   size_t n_blocks = pool / kLogicBlock;  // capacity; the launch uses what the schedule needs
@@ -842,20 +845,10 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     a.n_units = (uint32_t)n_units;
   }
   if (n_units > 0 && !fused) {
-    // static unit schedule (see k_logic): `lanes` pixel-list entries in flight,
-    // `per_pixel` slots sharing the chunks of one entry
-    // lanes divides the pixel list into equal passes, so every slot serves the
-    // same number of entries (+-1)
-    size_t passes = ((size_t)a.n_shade + pool_target - 1) / pool_target;
-    size_t lanes = ((size_t)a.n_shade + passes - 1) / passes;
-    size_t per_pixel = (pool_target + lanes / 2) / lanes;
-    if (per_pixel < 1) per_pixel = 1;
-    if (per_pixel > (size_t)a.n_chunks) per_pixel = a.n_chunks;
-    a.unit_lanes = (uint32_t)lanes;
-    a.unit_per_pixel = (uint32_t)per_pixel;
-    size_t used = lanes * per_pixel;
+    // no more slots than units (units are dealt on demand, see k_logic)
+    size_t used = std::min<size_t>(pool_target, (size_t)n_units);
     used = (used + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
-    if (used > pool) return fail(RTR_ERR_DEVICE, "internal: pool smaller than the unit schedule");
+    if (used > pool) return fail(RTR_ERR_DEVICE, "internal: pool smaller than planned");
     pool = used;
     n_blocks = pool / kLogicBlock;
   }
@@ -907,7 +900,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
           HIP_TRY(timed_on(streams[h], kLogic, [&] {
             hipLaunchKernelGGL(k_logic, dim3(ng * kGroup), dim3(kLogicBlock), 0, streams[h], a, s->ds,
                                s->dl, s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
-                               ws.partial.ptr, parity, (int)(g0 * kGroup));
+                               ws.partial.ptr, cnt, ws.wave_res.ptr, parity, (int)(g0 * kGroup));
           }));
           HIP_TRY(timed_on(streams[h], kTrace, [&] {
             if (s->lds_geometry)

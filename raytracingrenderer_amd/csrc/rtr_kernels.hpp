@@ -88,7 +88,6 @@ struct RenderArgs {
   int32_t chunk_spp, n_chunks, pool;
   uint32_t n_shade, n_units;  // wavefront loop only: read back after k_classify
   int32_t first;              // 1 on the first iteration: no slot has a unit yet
-  uint32_t unit_lanes, unit_per_pixel;  // static unit schedule, see k_logic
 };
 
 RTR_DEV unsigned lane_id() { return threadIdx.x & 63u; }
@@ -380,7 +379,7 @@ __global__ void __launch_bounds__(kLogicBlock)
 k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
         PixelCache pc, PathPool p, const uint32_t *__restrict__ shade_list,
         uint32_t *__restrict__ queue, BlockCounters *__restrict__ bc, float4 *__restrict__ partial,
-        int parity, int block_off) {
+        Counters *__restrict__ cnt, uint2 *__restrict__ wave_res, int parity, int block_off) {
   __shared__ unsigned s_count[4][kLogicWaves];
   const int blk = (int)blockIdx.x + block_off;  // the pool may be driven as several launches
   const int slot = blk * kLogicBlock + threadIdx.x;
@@ -443,49 +442,75 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     }
   }
 
-  // A slot without a live path starts the next sample of its unit, or its next
-  // unit.  Units are dealt statically and pixel-affine: the pool is `lanes` slot
-  // lanes times `per_pixel` slots; slot s serves pixel-list entries s % lanes,
-  // + lanes, + 2*lanes, ... and, within an entry, chunks s / lanes, + per_pixel, ...
-  // Neighbouring lanes of a wave therefore always restart at neighbouring pixels
-  // (coherent first vertices and shadow rays), every slot gets the same number of
-  // units, and no dispenser or atomic is involved.  unit_id = entry * n_chunks + chunk.
-  const unsigned lanes = a.unit_lanes, per_pixel = a.unit_per_pixel, nch = (unsigned)a.n_chunks;
+  // A slot without a live path starts the next sample of its unit, or asks for a new
+  // unit.  Units are handed out on demand, as in the fused kernel: a wave reserves
+  // 64 consecutive units with one atomic add on the global cursor, keeps what it has
+  // not dealt yet in its record of `wave_res` between launches, and deals by ballot
+  // rank.  (A static split per slot let the slots with the longest paths run on for
+  // a third more iterations than the average, with the pool mostly empty.)
+  // Unit u is chunk u / n_shade of pixel-list entry u % n_shade; 0xffffffff: none, and
+  // none to come.
   bool unit_finished = in_range && (flags & kHasUnit) && !(flags & kLive) && k >= k_end;
   bool unit_changed = false;
   if (unit_finished) {
-    unsigned chunk = unit_id % nch;
+    unsigned chunk = unit_id / a.n_shade;
     partial[(size_t)chunk * a.n_pix + lp] = pack(acc, 0.0f);
     flags &= ~kHasUnit;
   }
-  if (in_range && !(flags & kHasUnit) && (a.first || unit_id != 0xffffffffu)) {
-    unsigned entry, chunk;
-    if (a.first) {
-      entry = (unsigned)slot % lanes;
-      chunk = (unsigned)slot / lanes;
-      // the pool is rounded up to whole workgroup groups: slots past lanes * per_pixel
-      // get nothing (their chunk sequence would repeat that of the first slot row)
-      if (chunk >= per_pixel) chunk = nch;
-    } else {
-      entry = unit_id / nch;
-      chunk = unit_id - entry * nch + per_pixel;
-      if (chunk >= nch) {
-        chunk = (unsigned)slot / lanes;
-        entry += lanes;
+  {
+    const unsigned gw = (unsigned)slot >> 6;  // this wave's record
+    uint32_t res_base = 0, res_left = 0;
+    if (!a.first) {
+      const uint2 r = wave_res[gw];
+      res_base = r.x;
+      res_left = r.y;
+    }
+    bool drained = !a.first && res_left == 0 && res_base == 0xffffffffu;
+    bool touched = false;
+    bool need = in_range && !(flags & kHasUnit) && (a.first || unit_id != 0xffffffffu);
+    for (unsigned long long want = __ballot(need); want != 0; want = __ballot(need)) {
+      touched = true;
+      if (res_left == 0) {
+        if (!drained) {
+          unsigned long long base = 0;
+          if (lane_id() == 0) base = atomicAdd(&cnt->next_unit, 64ull);
+          base = __shfl(base, 0);
+          if (base >= a.n_units) {
+            drained = true;
+          } else {
+            res_base = (uint32_t)base;
+            res_left = min(64u, a.n_units - res_base);
+          }
+        }
+        if (drained) {
+          // nothing left anywhere: these slots are done for good
+          if (need) {
+            unit_id = 0xffffffffu;
+            unit_changed = true;
+            need = false;
+          }
+          res_base = 0xffffffffu;
+          break;
+        }
       }
+      const uint32_t rank = (uint32_t)__popcll(want & lanes_below());
+      if (need && rank < res_left) {
+        unit_id = res_base + rank;
+        const uint32_t entry = unit_id % a.n_shade, chunk = unit_id / a.n_shade;
+        lp = shade_list[entry];
+        k = chunk * (uint32_t)a.chunk_spp;
+        k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+        acc = mk(0, 0, 0);
+        gpix = wbits(pc.wi[lp]);
+        flags |= kHasUnit;
+        unit_changed = true;
+        need = false;
+      }
+      const uint32_t dealt = min((uint32_t)__popcll(want), res_left);
+      res_base += dealt;
+      res_left -= dealt;
     }
-    unit_changed = true;
-    if (entry < a.n_shade && chunk < nch) {
-      unit_id = entry * nch + chunk;
-      lp = shade_list[entry];
-      k = chunk * (uint32_t)a.chunk_spp;
-      k_end = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
-      acc = mk(0, 0, 0);
-      gpix = wbits(pc.wi[lp]);
-      flags |= kHasUnit;
-    } else {
-      unit_id = 0xffffffffu;  // this slot has no more work
-    }
+    if ((touched || a.first) && lane_id() == 0) wave_res[gw] = make_uint2(res_base, res_left);
   }
   bool live = in_range && (flags & kHasUnit);
   if (live && !(flags & kLive)) {
