@@ -68,10 +68,10 @@ struct Counters {
   unsigned long long next_unit;       // its cursor: first unit no wave has reserved yet
 };
 
-// The wavefront loop uses no global atomics.  Every k_logic workgroup owns one
-// record and one fixed segment of the ray queue; the host adds the records up.
-// (Per-wave, and then per-workgroup, atomics on shared counters used to be the
-// largest single cost of the path-logic kernel.)
+// The wavefront loop's only global atomic is the unit cursor (one add per 64 units).
+// Every k_logic workgroup owns one record and one fixed segment of the ray queue;
+// the host adds the records up.  (Per-wave, and then per-workgroup, atomics on
+// shared queue counters used to be the largest single cost of the path-logic kernel.)
 struct BlockCounters {
   unsigned int qcount[2][2];    // rays this workgroup queued: [iteration parity][0 shadow, 1 extension]
   unsigned int done;            // work units finished so far
