@@ -269,6 +269,26 @@ def test_render_bit_exact_vs_checker(scenes, W, H, spp, chunk, how):
     assert rgb.mean() > 0.05
 
 
+@pytest.mark.parametrize("how", MODES, ids=MODE_IDS)
+def test_render_edge_parameters(rt, scenes, how):
+    """One pixel, one sample; a chunk longer than the sample count; paths cut at the first
+    vertex; roulette that never stops a path; a partition that owns no column."""
+    O, so, sg = scenes
+    cases = [dict(W=1, H=1, spp=1), dict(W=8, H=8, spp=5, chunk_spp=7),
+             dict(W=24, H=16, spp=4, max_depth=1), dict(W=24, H=16, spp=3, max_depth=4, rr_prob=1.0)]
+    for cs in cases:
+        cs = dict(cs)
+        W, H, spp = cs.pop("W"), cs.pop("H"), cs.pop("spp")
+        rgb, st = sg.render(W, H, spp, seed=13, **cs, **how)
+        okw = dict(cs)
+        okw["chunk_spp"] = st.chunk_spp
+        want, stats = O.render(so, W, H, spp, seed=13, **okw)
+        _assert_images_equal(rgb, want)
+        assert (st.rays, st.vertices) == (stats[1], stats[3])
+    rgb, st = sg.render(8, 8, 2, part_index=3, part_count=4, tile_cols=8, **how)
+    assert rgb.shape == (0, 3) and st.samples == 0
+
+
 def test_render_independent_of_pool_and_partition(rt, scenes):
     O, so, sg = scenes
     W, H, spp = 80, 40, 6
