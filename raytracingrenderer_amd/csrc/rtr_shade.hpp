@@ -120,19 +120,21 @@ RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un) {
     float c = dot(uo, un);
     float f = c > 0.0f ? (float)(1.0f / kPi) : 0.0f;
     res = kd * f;
-  } else if (kind == 1) {
-    V3 h = ui + uo;
-    h = unit(h);
-    res = ((double)dot(h, un) > (double)1.0f - 1e-3) ? kd : mk(0, 0, 0);
   } else {
-    V3 ks = xyz(m.ks_rough);
-    float rough = m.ks_rough.w;
-    float kr = fresnel_kr(ui, un, m.kd_ior.w);
-    float d = ggx_d(rough, un, unit(ui + uo));
-    float g = smith_g(rough, un, ui, uo);
-    float co = dot(uo, un);
-    float ci = dot(ui, un);
-    res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + kd * (1 - kr) / (float)kPi;
+    // both remaining kinds start from the normalised half vector (src/Material.cpp:76-77, :86)
+    const V3 h = unit(ui + uo);
+    if (kind == 1) {
+      res = ((double)dot(h, un) > (double)1.0f - 1e-3) ? kd : mk(0, 0, 0);
+    } else {
+      V3 ks = xyz(m.ks_rough);
+      float rough = m.ks_rough.w;
+      float kr = fresnel_kr(ui, un, m.kd_ior.w);
+      float d = ggx_d(rough, un, h);
+      float g = smith_g(rough, un, ui, uo);
+      float co = dot(uo, un);
+      float ci = dot(ui, un);
+      res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + kd * (1 - kr) / (float)kPi;
+    }
   }
   return res;
 }
