@@ -8,10 +8,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <limits>
 #include <map>
 #include <stdexcept>
+#include <thread>
 
 // ---------------- vectors ----------------
 float Vector3f::getLen() const { return sqrtf(x * x + y * y + z * z); }
@@ -88,33 +90,84 @@ void BVH::destroy(BVHNode *n) {
   delete n;
 }
 
-BVHNode *BVH::build(std::vector<Object *> &objs) {
-  if (objs.empty()) return nullptr;
-  BVHNode *node = new BVHNode();
-  Bound3 all;
-  for (Object *o : objs) all.merge(o->getBound());
-  node->bound = all;
-  if (objs.size() == 1) {
-    node->object = objs[0];
+namespace {
+
+// One record of the array the build sorts: the object and its sort key at the current
+// node.  std::sort decides by comparison outcomes and positions only, so sorting these
+// records by `key` permutes them exactly as the reference's sort of the object pointers
+// with the comparator "centre(a).axis < centre(b).axis" does (src/BVH.cpp:42-55), ties
+// included, without recomputing two box centres per comparison.
+struct SortRecord {
+  float key;
+  Object *obj;
+};
+
+// Subtrees at least this large are built by a task of their own while tasks remain.
+const size_t kParallelBuildMin = 1 << 14;
+
+struct TreeBuilder {
+  std::vector<SortRecord> rec;
+
+  // Builds the subtree over rec[lo, hi).  Sorting a sub-range in place gives what the
+  // reference's copy of that half into a fresh vector gives (src/BVH.cpp:58-61): the
+  // sort sees the same sequence either way.  `top` receives the order after this node's
+  // own sort, the only one the reference applies to the caller's vector.
+  BVHNode *build(size_t lo, size_t hi, int spare_tasks, std::vector<Object *> *top) {
+    BVHNode *node = new BVHNode();
+    Bound3 all;
+    for (size_t k = lo; k < hi; k++) all.merge(rec[k].obj->getBound());
+    node->bound = all;
+    if (hi - lo == 1) {
+      node->object = rec[lo].obj;
+      return node;
+    }
+    const float ex = all.max.x - all.min.x, ey = all.max.y - all.min.y, ez = all.max.z - all.min.z;
+    const int axis = ex > ey ? (ex > ez ? 0 : 2) : (ey > ez ? 1 : 2);
+    for (size_t k = lo; k < hi; k++) {
+      Vector3f c = rec[k].obj->getBound().getCenterPos();
+      rec[k].key = axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+    }
+    std::sort(rec.begin() + lo, rec.begin() + hi,
+              [](const SortRecord &a, const SortRecord &b) { return a.key < b.key; });
+    if (top)
+      for (size_t k = lo; k < hi; k++) (*top)[k - lo] = rec[k].obj;
+    const size_t mid = lo + (hi - lo) / 2;
+    if (spare_tasks > 0 && hi - lo >= kParallelBuildMin) {
+      // the two halves touch disjoint ranges of rec
+      const int give = (spare_tasks - 1) / 2;
+      auto lower = std::async(std::launch::async,
+                              [this, lo, mid, give] { return build(lo, mid, give, nullptr); });
+      try {
+        node->right = build(mid, hi, spare_tasks - 1 - give, nullptr);
+      } catch (...) {
+        lower.wait();
+        throw;
+      }
+      node->left = lower.get();
+    } else {
+      node->left = build(lo, mid, 0, nullptr);
+      node->right = build(mid, hi, 0, nullptr);
+    }
     return node;
   }
-  const float ex = all.max.x - all.min.x, ey = all.max.y - all.min.y, ez = all.max.z - all.min.z;
-  const int axis = ex > ey ? (ex > ez ? 0 : 2) : (ey > ez ? 1 : 2);
-  auto key = [axis](Object *o) {
-    Vector3f c = o->getBound().getCenterPos();
-    return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
-  };
-  std::sort(objs.begin(), objs.end(), [&](Object *a, Object *b) { return key(a) < key(b); });
-  const size_t half = objs.size() / 2;
-  std::vector<Object *> lower(objs.begin(), objs.begin() + half);
-  std::vector<Object *> upper(objs.begin() + half, objs.end());
-  node->left = build(lower);
-  node->right = build(upper);
-  return node;
+};
+
+}  // namespace
+
+BVHNode *BVH::build(std::vector<Object *> &objs) {
+  if (objs.empty()) return nullptr;
+  TreeBuilder tb;
+  tb.rec.resize(objs.size());
+  for (size_t k = 0; k < objs.size(); k++) tb.rec[k] = SortRecord{0.f, objs[k]};
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  if (hw > 32) hw = 32;
+  return tb.build(0, objs.size(), (int)hw - 1, &objs);
 }
 
 void BVH::buildBVH(std::vector<Object *> &objs) {
   destroy(root);
+  root = nullptr;
   root = build(objs);
 }
 
@@ -193,8 +246,14 @@ namespace {
 
 struct Flattener {
   FlatScene &f;
-  std::map<const Object *, int> prim_of;
+  std::map<const Object *, int> prim_of;    // spheres: their primitive id
+  std::map<const Object *, int> mesh_base;  // meshes: primitive id of their first triangle
   std::map<const Material *, int> mat_of;
+
+  // a mesh's triangles take consecutive ids in the order of its index triples
+  int triangle_prim(const Object *mesh, const Trangle *t) const {
+    return mesh_base.at(mesh) + t->indexInMesh;
+  }
 
   int material_id(const Material *m) {
     auto it = mat_of.find(m);
@@ -245,9 +304,8 @@ struct Flattener {
     std::vector<const Trangle *> by_index(leaf_order.size(), nullptr);
     for (const Trangle *t : leaf_order) by_index[t->indexInMesh] = t;
     int mat = material_id(m->getMaterial());
+    mesh_base[m] = (int)f.prim_kind.size();
     for (const Trangle *t : by_index) {  // prim ids follow the index-triple order
-      int prim = (int)f.prim_kind.size();
-      prim_of[t] = prim;
       f.prim_kind.push_back(RTR_PRIM_TRIANGLE);
       f.prim_index.push_back((int)f.tri_area.size());
       f.prim_material.push_back(mat);
@@ -266,13 +324,14 @@ struct Flattener {
     }
   }
 
-  int add_node(const BVHNode *n) {
+  // `mesh` is the mesh whose nested tree n belongs to, null in the top-level tree
+  int add_node(const BVHNode *n, const Object *mesh = nullptr) {
     // a mesh leaf of the top-level tree is replaced by the mesh's own tree: its
     // root carries the same bound (include/Trangle.h:56), so the second box test
     // the reference performs there cannot change the outcome
     if (n->object && n->object->kind() == Object::MESH) {
       const BVHNode *inner = static_cast<const TrangleMesh *>(n->object)->getBVH()->getRoot();
-      if (inner) return add_node(inner);
+      if (inner) return add_node(inner, n->object);
     }
     int id = (int)f.node_prim.size();
     const float lo[3] = {n->bound.min.x, n->bound.min.y, n->bound.min.z};
@@ -285,10 +344,11 @@ struct Flattener {
     f.node_right.push_back(-1);
     f.node_prim.push_back(-1);
     if (n->object) {
-      f.node_prim[id] = prim_of.at(n->object);
+      f.node_prim[id] = mesh ? triangle_prim(mesh, static_cast<const Trangle *>(n->object))
+                             : prim_of.at(n->object);
     } else {
-      int l = add_node(n->left);
-      int r = add_node(n->right);
+      int l = add_node(n->left, mesh);
+      int r = add_node(n->right, mesh);
       f.node_left[id] = l;
       f.node_right[id] = r;
     }
@@ -361,7 +421,7 @@ const FlatScene &Scene::flatten() {
       flat.light_prim.push_back(-1);
       std::vector<const Trangle *> leaf_order;
       fl.collect_triangles(static_cast<TrangleMesh *>(l)->getBVH()->getRoot(), leaf_order);
-      for (const Trangle *t : leaf_order) flat.light_tris.push_back(fl.prim_of.at(t));
+      for (const Trangle *t : leaf_order) flat.light_tris.push_back(fl.triangle_prim(l, t));
     }
     flat.light_tri_begin.push_back((int32_t)flat.light_tris.size());
   }

@@ -71,6 +71,19 @@ def test_host_flatten_matches_checker_random_mesh(rt):
     assert list(tris) == leaf_order
 
 
+def test_host_flatten_matches_checker_grid_mesh_with_tied_keys(rt):
+    """A regular grid: whole columns of triangles share one box centre, so the tree depends
+    on how the reference's std::sort orders equal keys.  45 000 triangles also take the
+    host build through its concurrent subtree tasks, which must not change the result."""
+    spec = _rays.heightfield_spec(150)
+    so = Oracle().build_scene(spec)
+    sh = rt.HostScene.from_spec(spec)
+    fh, fo = sh.flatten(), so.flatten()
+    assert len(fh[3]) == 2 * (19 + 2 * 150 * 150) - 1    # one leaf per primitive
+    for a, b in zip(fh, fo):
+        assert np.array_equal(_rays.bits(a), _rays.bits(b))
+
+
 def _desc_for(rt, spec):
     """Build an rtr_scene_desc by hand (ctypes) from the host library's arrays."""
     class Desc(C.Structure):

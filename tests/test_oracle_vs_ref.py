@@ -100,6 +100,18 @@ def test_closest_hit_random_scene(both):
     assert _rays.same_bits(no, nr)[hit].all()
 
 
+def test_grid_mesh_with_tied_sort_keys(both):
+    """A regular height field: every column of triangles shares one box-centre key, so the
+    tree the reference builds depends on how its std::sort orders equal keys."""
+    O, R, _, _ = both
+    spec = _rays.heightfield_spec(60)
+    so, sr = O.build_scene(spec), R.build_scene(spec)
+    fo, fr = so.flatten(), sr.flatten()
+    assert len(fo[3]) == 2 * (19 + 2 * 60 * 60) - 1
+    for a, b in zip(fo, fr):
+        assert np.array_equal(_rays.bits(a), _rays.bits(b))
+
+
 def test_check_connectable(both):
     """Scene::checkConnectable, include/Scene.h:49-56: same booleans on surface-point pairs
     (about 40 % connected), degenerate pairs included; also on a random scene."""
