@@ -93,6 +93,12 @@ struct rtr_scene {
   int n_materials = 0;
   bool lds_geometry = false;  // scene small enough for the kernels to stage it in LDS
   int fused_grid = 0;         // resident workgroups of the fused sampling kernel (0: not queried yet)
+  int stream_grid = 0;        // the same for k_trace_api_stream
+  int queue_grid = 0;         // and for k_trace_queue_stream
+  // ray counters of the streaming traversal, used in rotation so that calls queued on
+  // different streams do not share one
+  DevBuf<unsigned long long> trace_next;
+  unsigned trace_next_turn = 0;
   Workspace ws;
   // scratch for the host-pointer entry points
   DevBuf<float> io_f[5];
@@ -100,6 +106,8 @@ struct rtr_scene {
 };
 
 namespace {
+
+constexpr unsigned kTraceCounters = 64;
 
 struct DeviceGuard {
   int prev = 0;
@@ -511,6 +519,7 @@ void rtr_scene_destroy(rtr_scene *s) {
   s->tri_prim.release(); s->sph_prim.release(); s->prim_kind_row.release();
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();
+  s->trace_next.release();
   for (auto &b : s->io_f) b.release();
   for (auto &b : s->io_i) b.release();
   if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
@@ -526,12 +535,25 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
   if (!d_org || !d_dir || !d_prim || !d_t) return fail(RTR_ERR_INVALID, "null ray or result array");
   if (n > (size_t)0x7fffffff * kBlock) return fail(RTR_ERR_INVALID, "batch too large");
   DeviceGuard guard(s->device);
-  if (s->lds_geometry)
+  if (s->lds_geometry) {
     hipLaunchKernelGGL(k_trace_api<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
-  else
-    hipLaunchKernelGGL(k_trace_api<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
-                       s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
+  } else {
+    if (s->stream_grid == 0) {
+      int per_cu = 0, cus = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_api_stream, kBlock, 0));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+      if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
+      s->stream_grid = per_cu * cus;
+    }
+    HIP_TRY(s->trace_next.reserve(kTraceCounters));
+    unsigned long long *next = s->trace_next.ptr + (s->trace_next_turn++ % kTraceCounters);
+    HIP_TRY(hipMemsetAsync(next, 0, sizeof(*next), (hipStream_t)stream));
+    unsigned grid = (unsigned)s->stream_grid;
+    if ((uint64_t)grid * kBlock > n) grid = (unsigned)blocks_for(n);
+    hipLaunchKernelGGL(k_trace_api_stream, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s->ds,
+                       d_org, d_dir, (unsigned long long)n, d_prim, d_t, d_pos, d_nrm, next);
+  }
   HIP_TRY(hipGetLastError());
   return RTR_OK;
 }
@@ -891,6 +913,19 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     const int n_halves = (n_groups >= 2 && prm->streams != 1) ? 2 : 1;
     const size_t grp_begin[3] = {0, n_halves == 2 ? n_groups / 2 : n_groups, n_groups};
     hipStream_t streams[2] = {st, s->stream2};
+    unsigned queue_grid = 0;
+    if (!s->lds_geometry) {
+      if (s->queue_grid == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_queue_stream, kBlock, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+        if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
+        s->queue_grid = per_cu * cus;
+      }
+      // no more waves than there could be 64-ray batches in a launch
+      const size_t most = (grp_begin[1] * kGroup * kSegment + kBlock - 1) / kBlock;
+      queue_grid = (unsigned)std::min<size_t>((size_t)s->queue_grid, std::max<size_t>(most, 1));
+    }
     for (;;) {
       for (int b = 0; b < batch; b++) {
         int parity = (int)(iters & 1);
@@ -907,8 +942,8 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
               hipLaunchKernelGGL(k_trace_queue<true>, dim3(ng * kGroupParts), dim3(kBlock), 0,
                                  streams[h], s->ds, pp, ws.queue.ptr, bc, parity, g0);
             else
-              hipLaunchKernelGGL(k_trace_queue<false>, dim3(ng * kGroupParts), dim3(kBlock), 0,
-                                 streams[h], s->ds, pp, ws.queue.ptr, bc, parity, g0);
+              hipLaunchKernelGGL(k_trace_queue_stream, dim3(queue_grid), dim3(kBlock), 0, streams[h],
+                                 s->ds, pp, ws.queue.ptr, bc, cnt, parity, g0 * kGroup, ng * kGroup);
           }));
           trace_launches++;
         }
@@ -987,3 +1022,13 @@ int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *
 }
 
 } /* extern "C" */
+
+#ifdef RTR_STREAM_STATS
+// development only: read and clear the counters of trace_stream
+extern "C" int rtr_debug_stream_stats(unsigned long long *out8) {
+  unsigned long long zero[8] = {0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtr::g_stream_stats), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rtr::g_stream_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

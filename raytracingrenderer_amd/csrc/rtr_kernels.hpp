@@ -66,6 +66,9 @@ struct Counters {
   unsigned int pad;
   unsigned long long vertices, rays;  // totals of the fused sampling kernel
   unsigned long long next_unit;       // its cursor: first unit no wave has reserved yet
+  // cursors of k_trace_queue_stream over the (workgroup, ray kind) queue segments of a
+  // launch, one per half of the pool; k_logic resets the one of its half
+  unsigned int trace_next[2];
 };
 
 // The wavefront loop's only global atomic is the unit cursor (one add per 64 units).
@@ -151,6 +154,61 @@ k_trace_api(DeviceScene sc, const float *__restrict__ org, const float *__restri
   if (h.leaf >= 0) hit_point(sc, h, o, dn, p, nn);
   if (pos) { pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z; }
   if (nrm) { nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z; }
+}
+
+// The same for scenes that do not fit LDS: a fixed number of resident waves pull rays
+// from the arrays through one counter (trace_stream), so no lane waits for the
+// longest ray of its wave.  *next must be 0 at launch.
+RTR_DEV uint32_t wave_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct RayArrays {
+  typedef unsigned long long Index;
+  typedef unsigned long long Tag;
+  const DeviceScene &sc;
+  const float *org, *dir;
+  unsigned long long n;
+  int32_t *prim;
+  float *t, *pos, *nrm;
+  unsigned long long *next;
+  RTR_DEV unsigned grab(Index &base, bool &more) const {
+    unsigned long long b = 0;
+    if ((threadIdx.x & 63u) == 0) b = atomicAdd(next, 64ull);
+    b = ((unsigned long long)wave_first((uint32_t)(b >> 32)) << 32) | wave_first((uint32_t)b);
+    base = b;
+    if (b + 64 >= n) more = false;
+    if (b >= n) return 0;
+    const unsigned long long left = n - b;
+    return left < 64 ? (unsigned)left : 64u;
+  }
+  RTR_DEV void load(Index i, V3 &o, V3 &d, Tag &tag) const {
+    o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    tag = i;
+  }
+  RTR_DEV void store(Tag i, int leaf, float th, V3 p, V3 nn) const {
+    HitRec h{th, 0.0f, 0.0f, leaf};
+    prim[i] = hit_prim(sc, h);
+    t[i] = th;
+    if (pos) { pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z; }
+    if (nrm) { nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z; }
+  }
+};
+
+#ifdef RTR_STREAM_WAVES
+#define RTR_STREAM_ATTR __attribute__((amdgpu_waves_per_eu(RTR_STREAM_WAVES, RTR_STREAM_WAVES)))
+#else
+#define RTR_STREAM_ATTR
+#endif
+__global__ void __launch_bounds__(kBlock) RTR_STREAM_ATTR
+k_trace_api_stream(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir,
+                   unsigned long long n, int32_t *__restrict__ prim, float *__restrict__ t,
+                   float *__restrict__ pos, float *__restrict__ nrm, unsigned long long *next) {
+  __shared__ StreamShared sh;
+  static_assert(kBlock == 256, "StreamShared holds four waves");
+  if (threadIdx.x == 0) sh.merge_lock = 0;
+  __syncthreads();
+  RayArrays src{sc, org, dir, n, prim, t, pos, nrm, next};
+  trace_stream(sc, src, sh);
 }
 
 // ---- Scene::checkConnectable, include/Scene.h:49-56 ----
@@ -261,6 +319,72 @@ k_trace_queue(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
   } else {
     p.hs[slot] = pack(hp, h.t);
   }
+}
+
+// The same for scenes that do not fit LDS (trace_stream): resident waves pull the queue
+// segments of the launch, one (k_logic workgroup, ray kind) at a time, through
+// cnt->trace_next[half], and refill their lanes from them.
+struct QueueRays {
+  typedef uint32_t Index;  // position in the queue array
+  typedef uint32_t Tag;    // queue entry: pool slot | extension ray << 31
+  const DeviceScene &sc;
+  PathPool p;
+  const uint32_t *queue;
+  BlockCounters *bc;
+  unsigned int *next;
+  int parity;
+  unsigned blk_begin, n_pairs;  // first k_logic workgroup of the launch; 2 x their number
+  unsigned pos, end;            // wave-uniform: unread entries of the current segment
+  RTR_DEV unsigned grab(Index &base, bool &more) {
+    while (pos == end) {
+      unsigned w = 0;
+      if (lane_id() == 0) w = atomicAdd(next, 1u);
+      w = wave_first(w);
+      if (w >= n_pairs) {
+        more = false;
+        return 0;
+      }
+      const unsigned b = blk_begin + (w >> 1), kind = w & 1u;
+      const unsigned c = wave_first(bc[b].qcount[parity][kind]);
+      if (lane_id() == 0 && c) bc[b].rays[kind] += c;  // only writer
+      pos = b * (unsigned)kSegment + kind * (unsigned)kLogicBlock;
+      end = pos + c;
+    }
+    base = pos;
+    const unsigned got = end - pos < 64u ? end - pos : 64u;
+    pos += got;
+    return got;
+  }
+  RTR_DEV void load(Index i, V3 &o, V3 &d, Tag &tag) const {
+    const uint32_t e = queue[i];
+    const uint32_t slot = e & 0x7fffffffu;
+    tag = e;
+    o = xyz(p.A[slot]);
+    d = xyz((e >> 31) ? p.K[slot] : p.J[slot]);
+  }
+  // world-space results, so the path logic needs neither the primitive nor the ray again
+  RTR_DEV void store(Tag e, int leaf, float t, V3 hp, V3 hn) const {
+    const uint32_t slot = e & 0x7fffffffu;
+    if (leaf < 0) hp = mk(__int_as_float(0x7fc00000), 0, 0);
+    if (e >> 31) {
+      HitRec h{t, 0.0f, 0.0f, leaf};
+      p.he[slot] = pack(hp, (uint32_t)hit_prim(sc, h));
+      if (leaf >= 0) p.he2[slot] = pack(unit(hn), 0.0f);
+    } else {
+      p.hs[slot] = pack(hp, t);
+    }
+  }
+};
+
+__global__ void __launch_bounds__(kBlock) RTR_STREAM_ATTR
+k_trace_queue_stream(DeviceScene sc, PathPool p, const uint32_t *__restrict__ queue,
+                     BlockCounters *__restrict__ bc, Counters *__restrict__ cnt, int parity,
+                     unsigned blk_begin, unsigned n_blk) {
+  __shared__ StreamShared sh;
+  if (threadIdx.x == 0) sh.merge_lock = 0;
+  __syncthreads();
+  QueueRays src{sc, p, queue, bc, &cnt->trace_next[blk_begin != 0], parity, blk_begin, 2 * n_blk, 0, 0};
+  trace_stream(sc, src, sh);
 }
 
 // ---- first vertex of every pixel; pixels that need no sampling are finished here ----
@@ -382,6 +506,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
         Counters *__restrict__ cnt, uint2 *__restrict__ wave_res, int parity, int block_off) {
   __shared__ unsigned s_count[4][kLogicWaves];
   const int blk = (int)blockIdx.x + block_off;  // the pool may be driven as several launches
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->trace_next[block_off != 0] = 0;
   const int slot = blk * kLogicBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
   const bool in_range = slot < a.pool;

@@ -409,6 +409,347 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
   return best;
 }
 
+// ---------------------------------------------------------------------------
+// Closest hit over a stream of rays, with lanes refilled as their rays finish.
+//
+// The reference's traversal culls nothing by distance, so the number of nodes a ray
+// visits varies by orders of magnitude with the ray (a ray that skims a large mesh
+// walks thousands of nodes, one that only meets the walls a few dozen).  With one
+// fixed ray per lane a wave lasts as long as its longest ray and most lanes idle
+// (31 % of lanes active on a 1 M-triangle height field).  Here a wave keeps pulling
+// rays from the stream: whenever few enough of its lanes are still walking, the
+// pending primitive tests are flushed, finished lanes write their result and take
+// the next rays.
+//
+// Box tests go through a filter first.  With y = RN(1/d), q' = RN(a*y) differs
+// from the IEEE quotient q = RN(a/d) by at most 3 ulp: |q' - q| <= 2^-22 |q'|
+// (y and the product each carry one rounding, q another; nothing under- or
+// overflows under the preconditions of slab_fast).  tnear and tfar are a max and
+// a min of such values, so each is within 2^-22 m of the reference's, m being the
+// largest of the six |q'|.  If the computed gap tfar' - tnear' exceeds 2^-20 m in
+// magnitude, the reference's "tnear <= tfar" has the sign of that gap; otherwise
+// (a few tests in a million) the exact test decides.
+//
+// A refill is kept short, because the whole wave stands still for it: ring entries
+// carry the leaf, so a flush needs one round trip to memory, not two; both rings are
+// flushed in one pass; a test that becomes its ray's best hit writes the hit's
+// position and normal while the primitive is in registers, so retiring a ray loads
+// nothing; and the next 64 rays of the wave are reserved and loaded into registers
+// long before they are handed out (lane to lane, ds_bpermute), so that neither the
+// stream counter nor the ray arrays are waited for.
+struct StreamWave {
+  float4 ray0[64], ray1[64];  // {o, d.x} {d.y, d.z, dn.x, dn.y}
+  float rayz[64];             // dn.z
+  unsigned long long key[64];
+  float4 hit0[64], hit1[64];  // {position, t} {normal as stored, bits(leaf)}
+  uint2 ring[2][128];         // {lane | node << 6, leaf}
+  unsigned long long nan_mask;
+};
+// Per workgroup.  The stack of the literal merge-tree evaluation is shared by the
+// waves of a workgroup (rays of other lanes stay live while one lane re-traces, so it
+// cannot overlay the rings as in WaveShared); a wave takes `merge_lock` to use it.
+struct StreamShared {
+  StreamWave wave[4];
+  MergeStack merge;
+  unsigned merge_lock;
+};
+
+// Trangle::intersect / Sphere::intersect on primitives already in registers.
+RTR_DEV bool hit_triangle_regs(float4 q0, float4 q1, float4 q2, V3 o, V3 dir, V3 dn, float &t,
+                               float &b1, float &b2) {
+  V3 p0 = xyz(q0), p1 = xyz(q1), p2 = xyz(q2), n = mk(q0.w, q1.w, q2.w);
+  if (dot(-dir, n) < 0) return false;
+  V3 e1 = p1 - p0, e2 = p2 - p0, s = o - p0;
+  V3 s1 = cross(dn, e2), s2 = cross(s, e1);
+  float se = dot(s1, e1);
+  float inv = 1 / se;
+  t = inv * dot(s2, e2);
+  b1 = inv * dot(s1, s);
+  b2 = inv * dot(s2, dn);
+  if ((double)t < -1e-5 || (double)b1 < -1e-5 || (double)b2 < -1e-5 ||
+      (double)(1 - b1 - b2) < -1e-5)
+    return false;
+  return true;
+}
+RTR_DEV bool hit_sphere_regs(float4 q, V3 org, V3 d, float &t) {
+  V3 c = xyz(q);
+  float r = q.w;
+  V3 o = org - c;
+  if (length(o) < r) return false;
+  float a = d.x * d.x + d.y * d.y + d.z * d.z;
+  float b = 2 * (o.x * d.x + o.y * d.y + o.z * d.z);
+  float cc = o.x * o.x + o.y * o.y + o.z * o.z - r * r;
+  float delta = b * b - 4 * a * cc;
+  if (delta < 0) return false;
+  float sq = sqrtf(delta);
+  float t1 = (-b + sq) / 2 / a;
+  float t2 = (-b - sq) / 2 / a;
+  if ((double)t1 < 1e-3) return false;
+  t = (t2 < 0) ? t1 : t2;
+  return true;
+}
+
+// One pass over up to 64 pending (lane, leaf) pairs: c0 from the triangle ring, then c1
+// from the sphere ring (c0 + c1 <= 64).
+RTR_DEV void stream_round(const DeviceScene &sc, StreamWave &ws, unsigned head0, unsigned c0,
+                          unsigned head1, unsigned c1) {
+  const unsigned lane = threadIdx.x & 63u;
+  if (lane >= c0 + c1) return;
+  const bool is_tri = lane < c0;
+  const uint2 e = is_tri ? ws.ring[0][(head0 + lane) & 127u] : ws.ring[1][(head1 + lane - c0) & 127u];
+  const unsigned r = e.x & 63u;
+  const int node = (int)(e.x >> 6);
+  const int leaf = (int)e.y;
+  const int row = leaf & 0x3fffffff;
+  // all loads first: one round trip for both kinds
+  const float4 *first = is_tri ? sc.tris + 3 * (size_t)row : sc.sphs + row;
+  const float4 q0 = first[0];
+  float4 q1 = q0, q2 = q0;
+  if (is_tri) {
+    q1 = first[1];
+    q2 = first[2];
+  }
+  const float4 a = ws.ray0[r], b = ws.ray1[r];
+  const V3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y), dn = mk(b.z, b.w, ws.rayz[r]);
+  float t = 0, b1 = 0, b2 = 0;
+  const bool hit = is_tri ? hit_triangle_regs(q0, q1, q2, o, d, dn, t, b1, b2) : hit_sphere_regs(q0, o, dn, t);
+  if (!hit) return;
+  if (t != t) {
+    atomicOr(&ws.nan_mask, 1ull << r);
+    return;
+  }
+  const unsigned long long key = hit_key(t, node);
+  atomicMin(&ws.key[r], key);
+  // LDS executes a wave's operations in order: every lane's min is in place here
+  if (ws.key[r] != key) return;
+  V3 pos, nrm;
+  if (is_tri) {  // as hit_point()
+    pos = xyz(q0) * (1 - b1 - b2) + xyz(q1) * b1 + xyz(q2) * b2;
+    nrm = mk(q0.w, q1.w, q2.w);
+  } else {
+    pos = o + dn * t;
+    nrm = unit(pos - xyz(q0));
+  }
+  ws.hit0[r] = make_float4(pos.x, pos.y, pos.z, t);
+  ws.hit1[r] = make_float4(nrm.x, nrm.y, nrm.z, __int_as_float(leaf));
+}
+
+RTR_DEV bool slab_filtered(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
+  const f32x2 px = {lo.x, hi.x}, py = {lo.y, hi.y}, pz = {lo.z, hi.z};
+  const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f32x2 yx = {y.x, y.x}, yy = {y.y, y.y}, yz = {y.z, y.z};
+  const f32x2 qx = (px - ox) * yx, qy = (py - oy) * yy, qz = (pz - oz) * yz;
+  const float nx = fminf(qx.x, qx.y), ny = fminf(qy.x, qy.y), nz = fminf(qz.x, qz.y);
+  const float fx = fmaxf(qx.x, qx.y), fy = fmaxf(qy.x, qy.y), fz = fmaxf(qz.x, qz.y);
+  const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(nx), fabsf(ny)), fabsf(nz)),
+                        fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)));
+  const float gap = tf - tn;
+  if (fabsf(gap) > m * 9.5367431640625e-07f) return gap > 0.0f;  // 2^-20
+  return slab_fast(lo, hi, o, d, y);
+}
+
+#ifndef RTR_REFILL_AT
+#define RTR_REFILL_AT 40
+#endif
+
+RTR_DEV void hit_point(const DeviceScene &sc, const HitRec &h, V3 o, V3 dn, V3 &pos, V3 &nrm);
+
+#ifdef RTR_STREAM_STATS
+// development only: [0] wave iterations, [1] lane visits, [2] refills, [3] rays,
+// [4] test rounds, [5] pairs tested
+__device__ unsigned long long g_stream_stats[8];
+#define RTR_STAT(k, v) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_stream_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define RTR_STAT(k, v) do { } while (0)
+#endif
+
+RTR_DEV float lane_read(float v, unsigned src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+RTR_DEV uint32_t lane_read(uint32_t v, unsigned src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+RTR_DEV unsigned long long lane_read(unsigned long long v, unsigned src_lane) {
+  return ((unsigned long long)lane_read((uint32_t)(v >> 32), src_lane) << 32) | lane_read((uint32_t)v, src_lane);
+}
+
+// Src provides, for a wave:
+//   unsigned grab(Index &base, bool &more)  -- all lanes call it; reserves up to 64 rays
+//       base .. base + n - 1 of the stream and returns n (wave-uniform); clears `more`
+//       when nothing is left beyond them (only then may n be 0);
+//   void load(Index idx, V3 &o, V3 &dir, Tag &tag) -- ray idx and whatever names its
+//       result slot (Tag is a 4- or 8-byte integer);
+//   void store(Tag tag, int leaf, float t, V3 pos, V3 nrm) -- the result: leaf is -1
+//       for a miss, else (kind << 30) | row with the hit's distance, position and normal
+//       (Intersection::postion / ::normal of src/Trangle.cpp:23-24, src/Sphere.cpp:25-26).
+// Must be called by all 64 lanes of the wave; returns when the stream is exhausted
+// and all of this wave's rays are stored.
+template <class Src>
+RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
+  typedef typename Src::Index Index;
+  typedef typename Src::Tag Tag;
+  const GlobalGeom g = global_geom(sc);
+  const int n_nodes = sc.n_nodes;
+  const bool fast_planes = sc.fast_planes != 0;
+  StreamWave &ws = sh.wave[threadIdx.x >> 6];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (lane == 0) ws.nan_mask = 0;
+  bool have = false, fast = false;
+  Tag tag = 0;
+  V3 o = mk(0, 0, 0), dir = mk(1, 1, 1), dn = mk(1, 1, 1), inv = mk(1, 1, 1);
+  unsigned head0 = 0, tail0 = 0, head1 = 0, tail1 = 0;  // wave-uniform ring cursors
+  // rays reserved ahead: lane l holds ray stage_base + l, for l < stage_n; the first
+  // stage_used of them have been handed out
+  bool more = true;  // the stream may hold rays beyond the reserved ones
+  Index stage_base = 0;
+  unsigned stage_n = 0, stage_used = 0;
+  V3 so = mk(0, 0, 0), sd = mk(1, 1, 1);
+  Tag stag = 0;
+  int i = n_nodes;
+  for (;;) {
+    const bool alive = have && i < n_nodes;
+    const unsigned n_alive = (unsigned)__popcll(__ballot(alive));
+    const bool supply = more || stage_used < stage_n;
+    if (n_alive == 0 || (supply && n_alive <= RTR_REFILL_AT)) {
+      RTR_STAT(2, 1);
+      // flush the pending primitive tests, so that finished rays are final
+      {
+        const unsigned c0 = tail0 - head0, c1 = tail1 - head1;
+        RTR_STAT(4, (c0 + c1 > 64u) ? 2 : (c0 + c1 > 0u ? 1 : 0));
+        RTR_STAT(5, c0 + c1);
+        if (c0 + c1 > 64u) {
+          stream_round(sc, ws, head0, c0, head1, 0u);
+          stream_round(sc, ws, head0, 0u, head1, c1);
+        } else if (c0 + c1 > 0u) {
+          stream_round(sc, ws, head0, c0, head1, c1);
+        }
+        head0 = tail0;
+        head1 = tail1;
+      }
+      const bool done = have && !alive;
+      int leaf = -1;
+      float t = 0;
+      V3 pos = mk(0, 0, 0), nrm = mk(0, 0, 0);
+      if (done && ws.key[lane] != ~0ull) {
+        const float4 h0 = ws.hit0[lane], h1 = ws.hit1[lane];
+        pos = xyz(h0);
+        t = h0.w;
+        nrm = xyz(h1);
+        leaf = __float_as_int(h1.w);
+      }
+      // rare: a NaN distance was seen -> literal merge tree, one lane at a time
+      unsigned long long need = ws.nan_mask & __ballot(done);
+      if (need) {
+        if (lane == 0) {
+          ws.nan_mask &= ~need;
+          while (atomicCAS(&sh.merge_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        while (need) {
+          int l = __ffsll((long long)need) - 1;
+          if ((int)lane == l) {
+            HitRec h = trace_tree(g, o, dir, dn, sh.merge);
+            leaf = h.leaf;
+            t = h.t;
+            pos = mk(0, 0, 0);
+            nrm = mk(0, 0, 0);
+            if (h.leaf >= 0) hit_point(sc, h, o, dn, pos, nrm);
+          }
+          need &= need - 1;
+        }
+        if (lane == 0) atomicExch(&sh.merge_lock, 0u);
+      }
+      if (done) {
+        src.store(tag, leaf, t, pos, nrm);
+        have = false;
+      }
+      // hand out reserved rays; when they run out reserve the next 64 (their loads are
+      // only waited for if lanes are still idle now, else at a later refill)
+      for (int pass = 0; pass < 2; pass++) {
+        const unsigned long long idle = __ballot(!have);
+        const unsigned want = (unsigned)__popcll(idle);
+        const unsigned avail = stage_n - stage_used;
+        const unsigned take = want < avail ? want : avail;
+        if (take) {
+          const unsigned rank = (unsigned)__popcll(idle & below);
+          const unsigned from = (stage_used + rank) & 63u;
+          const V3 no = mk(lane_read(so.x, from), lane_read(so.y, from), lane_read(so.z, from));
+          const V3 nd = mk(lane_read(sd.x, from), lane_read(sd.y, from), lane_read(sd.z, from));
+          const Tag nt = lane_read(stag, from);
+          if (!have && rank < take) {
+            tag = nt;
+            o = no;
+            dir = nd;
+            dn = unit(dir);
+            inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+            fast = fast_planes && fast_ray(o, dn);
+            ws.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
+            ws.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
+            ws.rayz[lane] = dn.z;
+            ws.key[lane] = ~0ull;
+            i = 0;
+            have = true;
+          }
+          stage_used += take;
+          RTR_STAT(3, take);
+        }
+        if (stage_used < stage_n || !more) break;
+        const unsigned got = src.grab(stage_base, more);
+        stage_n = got;
+        stage_used = 0;
+        if (lane < got) src.load(stage_base + lane, so, sd, stag);
+        if (want == take) break;
+      }
+      if (__ballot(have) == 0) break;  // nothing left in the stream and nothing in flight
+      continue;
+    }
+    RTR_STAT(0, 1);
+    RTR_STAT(1, n_alive);
+    bool cand = false;
+    int kind = 0, node = i, cleaf = 0;
+    if (alive) {
+      float4 lo = g.node_lo(i), hi = g.node_hi(i);
+      int skip = (int)wbits(lo);
+      int leaf = (int)wbits(hi);
+      bool pass;
+      if (fast) pass = slab_filtered(lo, hi, o, dn, inv);
+      else pass = slab(lo, hi, o, dn);
+      if (pass && leaf < 0) {
+        i = i + 1;
+      } else {
+        i = skip;  // missed box, or a leaf (whose subtree is itself)
+        cand = pass;
+        kind = leaf >> 30;
+        cleaf = leaf;
+      }
+    }
+    const unsigned long long m0 = __ballot(cand && kind == 0), m1 = __ballot(cand && kind != 0);
+    if (m0) {
+      if (cand && kind == 0)
+        ws.ring[0][(tail0 + __popcll(m0 & below)) & 127u] = make_uint2(lane | ((uint32_t)node << 6), (uint32_t)cleaf);
+      tail0 += (unsigned)__popcll(m0);
+      if (tail0 - head0 >= 64u) {
+        RTR_STAT(4, 1);
+        RTR_STAT(5, 64);
+        stream_round(sc, ws, head0, 64u, head1, 0u);
+        head0 += 64u;
+      }
+    }
+    if (m1) {
+      if (cand && kind != 0)
+        ws.ring[1][(tail1 + __popcll(m1 & below)) & 127u] = make_uint2(lane | ((uint32_t)node << 6), (uint32_t)cleaf);
+      tail1 += (unsigned)__popcll(m1);
+      if (tail1 - head1 >= 64u) {
+        RTR_STAT(4, 1);
+        RTR_STAT(5, 64);
+        stream_round(sc, ws, head0, 0u, head1, 64u);
+        head1 += 64u;
+      }
+    }
+  }
+}
+
 // Geometry staged in LDS by a whole workgroup (kernels call this before tracing,
 // every thread of the block, then __syncthreads()).
 constexpr int kLdsNodes = 64, kLdsTris = 48, kLdsSphs = 32;
