@@ -136,7 +136,7 @@ typedef struct rtr_render_params {
   int32_t max_depth;  /* <=0: unbounded */
   float rr_prob;      /* <=0: 0.6f */
   int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: ceil(spp / 128) */
-  int32_t pool_size;  /* wavefront mode: concurrent paths; <=0: auto (about 2 M) */
+  int32_t pool_size;  /* wavefront mode: concurrent paths; <=0: auto (2^21, or 2^22 for scenes too large for LDS) */
   int32_t part_index, part_count, tile_cols;
   int32_t profile;    /* 1: bracket every kernel with events on the launch stream */
   int32_t mode;       /* RTR_MODE_*; 0: chosen from the scene's size */

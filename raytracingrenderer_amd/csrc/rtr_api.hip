@@ -95,6 +95,7 @@ struct rtr_scene {
   int fused_grid = 0;         // resident workgroups of the fused sampling kernel (0: not queried yet)
   int stream_grid = 0;        // the same for k_trace_api_stream
   int queue_grid = 0;         // and for k_trace_queue_stream
+  int connect_grid = 0;       // and for k_check_connectable_stream
   // ray counters of the streaming traversal, used in rotation so that calls queued on
   // different streams do not share one
   DevBuf<unsigned long long> trace_next;
@@ -140,6 +141,27 @@ float sqrt_threshold(float r) {
 }
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// Launch shape and ray counter of a streaming traversal kernel over n rays: as many
+// workgroups as stay resident (never more than n needs), and the next of the scene's
+// rotating counters, zeroed on `stream` ahead of the launch.
+template <class Kernel>
+int stream_launch(rtr_scene *s, Kernel kernel, int &cached_grid, size_t n, hipStream_t stream,
+                  unsigned &grid, unsigned long long *&next) {
+  if (cached_grid == 0) {
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+    if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
+    cached_grid = per_cu * cus;
+  }
+  HIP_TRY(s->trace_next.reserve(kTraceCounters));
+  next = s->trace_next.ptr + (s->trace_next_turn++ % kTraceCounters);
+  HIP_TRY(hipMemsetAsync(next, 0, sizeof(*next), stream));
+  grid = (unsigned)cached_grid;
+  if ((uint64_t)grid * kBlock > n) grid = blocks_for(n);
+  return RTR_OK;
+}
 
 // src/Render.cpp:639-649: the camera basis and per-pixel steps, in the
 // reference's mixed float/double arithmetic.
@@ -539,18 +561,10 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
     hipLaunchKernelGGL(k_trace_api<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
   } else {
-    if (s->stream_grid == 0) {
-      int per_cu = 0, cus = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_api_stream, kBlock, 0));
-      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
-      if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
-      s->stream_grid = per_cu * cus;
-    }
-    HIP_TRY(s->trace_next.reserve(kTraceCounters));
-    unsigned long long *next = s->trace_next.ptr + (s->trace_next_turn++ % kTraceCounters);
-    HIP_TRY(hipMemsetAsync(next, 0, sizeof(*next), (hipStream_t)stream));
-    unsigned grid = (unsigned)s->stream_grid;
-    if ((uint64_t)grid * kBlock > n) grid = (unsigned)blocks_for(n);
+    unsigned grid = 0;
+    unsigned long long *next = nullptr;
+    int rc = stream_launch(s, k_trace_api_stream, s->stream_grid, n, (hipStream_t)stream, grid, next);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_trace_api_stream, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s->ds,
                        d_org, d_dir, (unsigned long long)n, d_prim, d_t, d_pos, d_nrm, next);
   }
@@ -693,12 +707,18 @@ int rtr_check_connectable(rtr_scene *s, const float *a_xyz, const float *b_xyz, 
   HIP_TRY(hipMemcpyAsync(s->io_f[0].ptr, a_xyz, 12 * count, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->io_f[1].ptr, b_xyz, 12 * count, hipMemcpyHostToDevice, s->stream));
   unsigned char *out = (unsigned char *)s->io_i[0].ptr;
-  if (s->lds_geometry)
+  if (s->lds_geometry) {
     hipLaunchKernelGGL(k_check_connectable<true>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
                        s->ds, (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr, count, out);
-  else
-    hipLaunchKernelGGL(k_check_connectable<false>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
-                       s->ds, (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr, count, out);
+  } else {
+    unsigned grid = 0;
+    unsigned long long *next = nullptr;
+    int rc = stream_launch(s, k_check_connectable_stream, s->connect_grid, count, s->stream, grid, next);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_check_connectable_stream, dim3(grid), dim3(kBlock), 0, s->stream, s->ds,
+                       (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr,
+                       (unsigned long long)count, out, next);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(connected, out, count, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -750,7 +770,11 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
   // upper bound of the pool; the exact size follows from the number of pixels
   // that need sampling (known after k_classify)
-  size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size : ((size_t)1 << 21);
+  // (measured: 2^21 slots is best where the scene sits in LDS, 2^22 where traversal reads it
+  // from memory -- its launches then carry enough rays to amortise their tails; larger
+  // pools lose more in the path-logic kernels' cache behaviour than they gain)
+  size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size
+                                          : ((size_t)1 << (s->lds_geometry ? 21 : 22));
   size_t pool = pool_target;
   if (pool > max_units) pool = max_units;
   pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);

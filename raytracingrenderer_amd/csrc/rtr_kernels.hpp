@@ -238,6 +238,50 @@ k_check_connectable(DeviceScene sc, const float *__restrict__ a3, const float *_
   connected[i] = (h.leaf >= 0 && (double)fabsf(h.t - length(ab)) < 1e-3) ? 1 : 0;
 }
 
+// The same for scenes that do not fit LDS (trace_stream); *next must be 0 at launch.
+struct ConnectPairs {
+  typedef unsigned long long Index;
+  typedef unsigned long long Tag;
+  const float *a3, *b3;
+  unsigned long long n;
+  unsigned char *connected;
+  unsigned long long *next;
+  RTR_DEV unsigned grab(Index &base, bool &more) const {
+    unsigned long long b = 0;
+    if ((threadIdx.x & 63u) == 0) b = atomicAdd(next, 64ull);
+    b = ((unsigned long long)wave_first((uint32_t)(b >> 32)) << 32) | wave_first((uint32_t)b);
+    base = b;
+    if (b + 64 >= n) more = false;
+    if (b >= n) return 0;
+    const unsigned long long left = n - b;
+    return left < 64 ? (unsigned)left : 64u;
+  }
+  RTR_DEV V3 span(Index i, V3 &a) const {
+    a = mk(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
+    return mk(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]) - a;
+  }
+  RTR_DEV void load(Index i, V3 &o, V3 &d, Tag &tag) const {
+    d = unit(span(i, o));  // Ray(a, (b - a).normalize())
+    tag = i;
+  }
+  RTR_DEV void store(Tag i, int leaf, float t, V3, V3) const {
+    V3 a;
+    const V3 ab = span(i, a);
+    connected[i] = (leaf >= 0 && (double)fabsf(t - length(ab)) < 1e-3) ? 1 : 0;
+  }
+};
+
+__global__ void __launch_bounds__(kBlock) RTR_STREAM_ATTR
+k_check_connectable_stream(DeviceScene sc, const float *__restrict__ a3, const float *__restrict__ b3,
+                           unsigned long long n, unsigned char *__restrict__ connected,
+                           unsigned long long *next) {
+  __shared__ StreamShared sh;
+  if (threadIdx.x == 0) sh.merge_lock = 0;
+  __syncthreads();
+  ConnectPairs src{a3, b3, n, connected, next};
+  trace_stream(sc, src, sh);
+}
+
 // ---- traversal of the primary rays (one per pixel, shared by all its samples) ----
 template <bool kLds>
 __global__ void __launch_bounds__(kBlock)

@@ -442,7 +442,8 @@ struct StreamWave {
   float rayz[64];             // dn.z
   unsigned long long key[64];
   float4 hit0[64], hit1[64];  // {position, t} {normal as stored, bits(leaf)}
-  uint2 ring[2][128];         // {lane | node << 6, leaf}
+  uint2 ring[2][128];         // {ray slot | node << 6, leaf}
+  unsigned int parts[64];     // lanes currently walking a part of the slot's node range
   unsigned long long nan_mask;
 };
 // Per workgroup.  The stack of the literal merge-tree evaluation is shared by the
@@ -552,6 +553,14 @@ RTR_DEV bool slab_filtered(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
 #ifndef RTR_REFILL_AT
 #define RTR_REFILL_AT 40
 #endif
+// once the stream is dry: split node ranges when at most this many lanes still walk,
+// and only ranges of at least RTR_SPLIT_MIN nodes
+#ifndef RTR_SPLIT_AT
+#define RTR_SPLIT_AT 32
+#endif
+#ifndef RTR_SPLIT_MIN
+#define RTR_SPLIT_MIN 128
+#endif
 
 RTR_DEV void hit_point(const DeviceScene &sc, const HitRec &h, V3 o, V3 dn, V3 &pos, V3 &nrm);
 
@@ -592,13 +601,19 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
   const GlobalGeom g = global_geom(sc);
   const int n_nodes = sc.n_nodes;
   const bool fast_planes = sc.fast_planes != 0;
+  const bool can_split = sc.nested_boxes != 0;
   StreamWave &ws = sh.wave[threadIdx.x >> 6];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
   if (lane == 0) ws.nan_mask = 0;
+  ws.parts[lane] = 0;
+  // `have`: this lane's slot holds a ray whose result is not stored yet (tag names it).
+  // The lane walks nodes [i, end) for the ray in slot r: its own (r == lane), or, once
+  // the stream has run dry, half of another lane's remaining range.
   bool have = false, fast = false;
   Tag tag = 0;
-  V3 o = mk(0, 0, 0), dir = mk(1, 1, 1), dn = mk(1, 1, 1), inv = mk(1, 1, 1);
+  unsigned r = lane;
+  V3 o = mk(0, 0, 0), dn = mk(1, 1, 1), inv = mk(1, 1, 1);
   unsigned head0 = 0, tail0 = 0, head1 = 0, tail1 = 0;  // wave-uniform ring cursors
   // rays reserved ahead: lane l holds ray stage_base + l, for l < stage_n; the first
   // stage_used of them have been handed out
@@ -607,12 +622,16 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
   unsigned stage_n = 0, stage_used = 0;
   V3 so = mk(0, 0, 0), sd = mk(1, 1, 1);
   Tag stag = 0;
-  int i = n_nodes;
+  int i = 0, end = 0;
   for (;;) {
-    const bool alive = have && i < n_nodes;
-    const unsigned n_alive = (unsigned)__popcll(__ballot(alive));
+    const bool alive = i < end;
+    const unsigned long long alive_mask = __ballot(alive);
+    const unsigned n_alive = (unsigned)__popcll(alive_mask);
     const bool supply = more || stage_used < stage_n;
-    if (n_alive == 0 || (supply && n_alive <= RTR_REFILL_AT)) {
+    bool event = n_alive == 0 || (supply && n_alive <= RTR_REFILL_AT);
+    if (!event && !supply && can_split && n_alive <= RTR_SPLIT_AT)
+      event = __ballot(alive && fast && end - i >= RTR_SPLIT_MIN) != 0;
+    if (event) {
       RTR_STAT(2, 1);
       // flush the pending primitive tests, so that finished rays are final
       {
@@ -628,7 +647,14 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
         head0 = tail0;
         head1 = tail1;
       }
-      const bool done = have && !alive;
+      // a lane that reached the end of its range leaves its ray; a ray no lane works on
+      // any more is finished (LDS operations of a wave execute in order)
+      if (!alive && end > 0) {
+        atomicSub(&ws.parts[r], 1u);
+        end = 0;
+        i = 0;
+      }
+      const bool done = have && ws.parts[lane] == 0;
       int leaf = -1;
       float t = 0;
       V3 pos = mk(0, 0, 0), nrm = mk(0, 0, 0);
@@ -649,12 +675,14 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
         while (need) {
           int l = __ffsll((long long)need) - 1;
           if ((int)lane == l) {
-            HitRec h = trace_tree(g, o, dir, dn, sh.merge);
+            const float4 a0 = ws.ray0[lane], a1 = ws.ray1[lane];
+            const V3 ro = mk(a0.x, a0.y, a0.z), rd = mk(a0.w, a1.x, a1.y), rn = mk(a1.z, a1.w, ws.rayz[lane]);
+            HitRec h = trace_tree(g, ro, rd, rn, sh.merge);
             leaf = h.leaf;
             t = h.t;
             pos = mk(0, 0, 0);
             nrm = mk(0, 0, 0);
-            if (h.leaf >= 0) hit_point(sc, h, o, dn, pos, nrm);
+            if (h.leaf >= 0) hit_point(sc, h, ro, rn, pos, nrm);
           }
           need &= need - 1;
         }
@@ -666,7 +694,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
       }
       // hand out reserved rays; when they run out reserve the next 64 (their loads are
       // only waited for if lanes are still idle now, else at a later refill)
-      for (int pass = 0; pass < 2; pass++) {
+      for (int pass = 0; pass < 2 && supply; pass++) {
         const unsigned long long idle = __ballot(!have);
         const unsigned want = (unsigned)__popcll(idle);
         const unsigned avail = stage_n - stage_used;
@@ -680,15 +708,17 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
           if (!have && rank < take) {
             tag = nt;
             o = no;
-            dir = nd;
-            dn = unit(dir);
+            dn = unit(nd);
             inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
             fast = fast_planes && fast_ray(o, dn);
-            ws.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
-            ws.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
+            ws.ray0[lane] = make_float4(o.x, o.y, o.z, nd.x);
+            ws.ray1[lane] = make_float4(nd.y, nd.z, dn.x, dn.y);
             ws.rayz[lane] = dn.z;
             ws.key[lane] = ~0ull;
+            ws.parts[lane] = n_nodes > 0 ? 1u : 0u;  // an empty tree: finished at once
+            r = lane;
             i = 0;
+            end = n_nodes;
             have = true;
           }
           stage_used += take;
@@ -701,7 +731,43 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
         if (lane < got) src.load(stage_base + lane, so, sd, stag);
         if (want == take) break;
       }
-      if (__ballot(have) == 0) break;  // nothing left in the stream and nothing in flight
+      // The stream is dry: idle lanes take the upper half of the node range of lanes
+      // that still walk.  Any node may start a walk when boxes are nested and the ray's
+      // arithmetic is finite (fast): a box that passes implies that all its ancestors
+      // pass (their near/far quotients enclose the child's, rounding being monotone), so
+      // nodes below a missed box miss as well and no test is made that the reference
+      // would not make; results merge through the order-independent key minimum.
+      if (!(more || stage_used < stage_n) && can_split) {
+        const bool victim = i < end && fast && end - i >= RTR_SPLIT_MIN;
+        const bool thief = !(i < end);
+        const unsigned long long vm = __ballot(victim), tm = __ballot(thief);
+        const unsigned nv = (unsigned)__popcll(vm), nt = (unsigned)__popcll(tm);
+        const unsigned pairs = nv < nt ? nv : nt;
+        if (pairs) {
+          RTR_STAT(6, pairs);
+          // the rings are empty here: their storage carries the hand-over
+          const unsigned vr = (unsigned)__popcll(vm & below), tr = (unsigned)__popcll(tm & below);
+          if (victim && vr < pairs) {
+            const int mid = i + (end - i) / 2;
+            ws.ring[0][vr] = make_uint2((uint32_t)mid, (uint32_t)end);
+            ws.ring[1][vr].x = r;
+            atomicAdd(&ws.parts[r], 1u);
+            end = mid;
+          }
+          if (thief && tr < pairs) {
+            const uint2 range = ws.ring[0][tr];
+            r = ws.ring[1][tr].x;
+            i = (int)range.x;
+            end = (int)range.y;
+            const float4 a0 = ws.ray0[r], a1 = ws.ray1[r];
+            o = mk(a0.x, a0.y, a0.z);
+            dn = mk(a1.z, a1.w, ws.rayz[r]);
+            inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+            fast = true;
+          }
+        }
+      }
+      if ((__ballot(have) | __ballot(i < end)) == 0) break;  // stream dry, nothing in flight
       continue;
     }
     RTR_STAT(0, 1);
@@ -727,7 +793,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
     const unsigned long long m0 = __ballot(cand && kind == 0), m1 = __ballot(cand && kind != 0);
     if (m0) {
       if (cand && kind == 0)
-        ws.ring[0][(tail0 + __popcll(m0 & below)) & 127u] = make_uint2(lane | ((uint32_t)node << 6), (uint32_t)cleaf);
+        ws.ring[0][(tail0 + __popcll(m0 & below)) & 127u] = make_uint2(r | ((uint32_t)node << 6), (uint32_t)cleaf);
       tail0 += (unsigned)__popcll(m0);
       if (tail0 - head0 >= 64u) {
         RTR_STAT(4, 1);
@@ -738,7 +804,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
     }
     if (m1) {
       if (cand && kind != 0)
-        ws.ring[1][(tail1 + __popcll(m1 & below)) & 127u] = make_uint2(lane | ((uint32_t)node << 6), (uint32_t)cleaf);
+        ws.ring[1][(tail1 + __popcll(m1 & below)) & 127u] = make_uint2(r | ((uint32_t)node << 6), (uint32_t)cleaf);
       tail1 += (unsigned)__popcll(m1);
       if (tail1 - head1 >= 64u) {
         RTR_STAT(4, 1);

@@ -109,6 +109,12 @@ def test_million_triangle_mesh(rt):
     want = so.intersect(org, d)
     _assert_hits_equal(sg.intersect(org, d), want)
     assert (want[0] >= 19).mean() > 0.1  # tens of thousands of rays end on the mesh
+    # a handful of rays that skim the field and walk thousands of nodes each: with so few
+    # rays in the wave their node ranges are split over its idle lanes
+    rng = np.random.default_rng(3)
+    so_ = np.stack([rng.uniform(30, 60, 150), rng.uniform(50, 95, 150), rng.uniform(-60, -30, 150)], 1).astype(f32)
+    sd_ = np.stack([rng.uniform(0.5, 1, 150), rng.uniform(-0.03, 0.03, 150), rng.uniform(-1, -0.5, 150)], 1).astype(f32)
+    _assert_hits_equal(sg.intersect(so_, sd_), so.intersect(so_, sd_))
     img, stats = O.render(so, 32, 32, 4, seed=9, chunk_spp=2)
     for how in (dict(mode=1), dict(mode=2)):
         rgb, st = sg.render(32, 32, 4, seed=9, chunk_spp=2, **how)
@@ -140,6 +146,36 @@ def test_closest_hit_degenerate_triangles_nan_distance(rt):
     d = np.concatenate([ad, extra_d, idr])
     want = so.intersect(org, d)
     _assert_hits_equal(sg.intersect(org, d), want)
+
+
+def test_degenerate_triangles_in_a_large_scene(rt):
+    """The same inf/NaN distances where traversal streams rays through a tree in memory:
+    rays that met a NaN are re-traced with the literal merge order."""
+    O = Oracle()
+    spec = _random_scene_spec(5)
+    verts = np.array([[100, 100, -200], [200, 100, -200], [300, 100, -200],   # collinear
+                      [50, 50, -50], [50, 50, -50], [50, 50, -50],            # a point
+                      [0, 300, -300], [512, 300, -300], [256, 300, -100],     # in a y-plane
+                      [256, 0, -300], [256, 512, -300], [256, 256, -100]], f32)  # in an x-plane
+    spec["objects"] = spec["objects"] + [("mesh", "white", verts, np.arange(12, dtype=np.uint32))]
+    so = O.build_scene(spec)
+    sg = rt.HostScene.from_spec(spec)
+    ao, ad = _rays.adversarial_rays()
+    extra_o = np.array([[0, 300, -200], [256, 100, -200], [0, 300, -300], [256, 0, -300],
+                        [600, 300, -250], [256, 600, -250]], f32)
+    extra_d = np.array([[1, 0, 0], [0, 1, 0], [1, 0, 1], [0, 1, 1], [-1, 0, 0.2], [0, -1, 0.2]], f32)
+    io, idr = _rays.interior_rays(20000, seed=78)
+    # rays inside the planes of the edge-on triangles, many of them, from all around
+    rng = np.random.default_rng(8)
+    k = 3000
+    ang = rng.uniform(0, 2 * np.pi, k)
+    po = np.stack([rng.uniform(0, 512, k), np.full(k, 300.0), rng.uniform(-512, 0, k)], 1).astype(f32)
+    pd = np.stack([np.cos(ang), np.zeros(k), np.sin(ang)], 1).astype(f32)
+    org = np.concatenate([ao, extra_o, io, po])
+    d = np.concatenate([ad, extra_d, idr, pd])
+    want = so.intersect(org, d)
+    _assert_hits_equal(sg.intersect(org, d), want)
+    assert np.isnan(want[1][want[0] >= 0]).any() or np.isinf(want[1][want[0] >= 0]).any()
 
 
 def test_check_connectable(rt, scenes):

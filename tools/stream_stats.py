@@ -10,10 +10,10 @@ lib = rt.hip_lib()
 def stats(label):
     out = (C.c_ulonglong * 8)()
     assert lib.rtr_debug_stream_stats(out) == 0
-    it, vis, ev, rays, rounds, pairs = [int(x) for x in out[:6]]
+    it, vis, ev, rays, rounds, pairs, splits = [int(x) for x in out[:7]]
     if rays:
-        print("%s: rays %d  visits/ray %.1f  lanes alive per iteration %.1f  iterations/refill %.1f  rays/refill %.1f  pairs/ray %.2f  pairs/round %.1f"
-              % (label, rays, vis / rays, vis / max(it, 1), it / max(ev, 1), rays / max(ev, 1), pairs / rays, pairs / max(rounds, 1)), flush=True)
+        print("%s: rays %d  visits/ray %.1f  lanes alive per iteration %.1f  iterations/refill %.1f  rays/refill %.1f  pairs/ray %.2f  pairs/round %.1f  splits/ray %.3f"
+              % (label, rays, vis / rays, vis / max(it, 1), it / max(ev, 1), rays / max(ev, 1), pairs / rays, pairs / max(rounds, 1), splits / rays), flush=True)
 sg = rt.HostScene.from_spec(_rays.heightfield_spec(708))
 nr = 1 << 22
 org, d = _rays.interior_rays(nr, seed=5)

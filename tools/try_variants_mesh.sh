@@ -1,10 +1,11 @@
 #!/bin/bash
-# Development helper: tools/bench_mesh.py with alternative builds of the HIP library
+# Development helper: large-scene benches with alternative builds of the HIP library
 # (raytracingrenderer_amd/librtr_hip_<name>.so), restoring the default one afterwards.
 cd $GRAFT_REPO_ROOT
 cp raytracingrenderer_amd/librtr_hip.so /tmp/librtr_hip_keep.so
 for n in "$@"; do
   cp raytracingrenderer_amd/librtr_hip_$n.so raytracingrenderer_amd/librtr_hip.so
   echo "== $n"; timeout -k 10 120 python -u tools/bench_mesh.py 2>&1 | tail -1
+  timeout -k 10 120 python -u tools/bench_mesh_render.py 708 64 2>&1 | head -2 | tail -1
 done
 cp /tmp/librtr_hip_keep.so raytracingrenderer_amd/librtr_hip.so
