@@ -203,6 +203,31 @@ int rtr_check_connectable(rtr_scene *scene, const float *a_xyz, const float *b_x
                           uint8_t *connected);
 
 /*
+ * Render::createPhotonMap (src/Render.cpp:405-481), the photon emission pass of the
+ * reference's photon-mapping integrator: sample a light point (Scene::samplingLight),
+ * bounce with Material::sample / Material::eval, store a photon {position, incoming
+ * direction, power} at every non-emissive hit reached from a DIFFUSE vertex, continue
+ * with probability 0.6 (always from non-DIFFUSE vertices), at most 65 bounces.
+ * The reference fills photonMap[k] sequentially from one shared generator (and from 16
+ * racing threads when photon_num >= 16).  Here emission path p draws bounce b's
+ * uniforms from the Philox stream (p, 0, b, block) under key (seed, 1), and the map is
+ * the first photon_num photons of paths 0, 1, 2, ... in path order: what one reference
+ * thread computes from those draws, bit for bit.  Arrays hold photon_num rows of x,y,z
+ * in host memory; *n_stored (may be NULL) = rows written (photon_num, or 0 for a scene
+ * without lights, where the reference leaves its map empty); *paths_used (may be NULL)
+ * = emission paths the map took.  A scene whose lights never deposit a photon makes the
+ * reference loop for ever; here it is an error.
+ */
+int rtr_create_photon_map(rtr_scene *scene, uint64_t photon_num, uint32_t seed, float *pos_xyz,
+                          float *wi_xyz, float *power_xyz, uint64_t *n_stored,
+                          uint32_t *paths_used);
+/* The same with the three arrays in device memory; returns after synchronising the
+ * scene's stream. */
+int rtr_create_photon_map_device(rtr_scene *scene, uint64_t photon_num, uint32_t seed,
+                                 float *d_pos_xyz, float *d_wi_xyz, float *d_power_xyz,
+                                 uint64_t *n_stored, uint32_t *paths_used);
+
+/*
  * Material::eval / Material::pdf / Material::sample (src/Material.cpp:66-168) on
  * the device, one row per query.  u2: the two uniforms Material::sample would
  * draw, in draw order (alph, theta).  Any output may be NULL.

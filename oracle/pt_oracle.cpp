@@ -590,13 +590,14 @@ struct VertexStream {
   uint32_t seed, pixel, sample, bounce, dim;
   uint32_t cache[4];
   int cached_block;
-  VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo)
-      : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), cached_block(-1) {}
+  uint32_t key1; /* 0: path tracing; 1: photon paths (pixel = path index, sample = 0) */
+  VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo, uint32_t k1 = 0)
+      : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), cached_block(-1), key1(k1) {}
   float operator()() {
     int blk = (int)(dim >> 2);
     if (blk != cached_block) {
       uint32_t c[4] = {pixel, sample, bounce, (uint32_t)blk};
-      uint32_t k[2] = {seed, 0};
+      uint32_t k[2] = {seed, key1};
       philox10(c, k, cache);
       cached_block = blk;
     }
@@ -692,6 +693,81 @@ V3 trace_forward(const orc_scene *s, V3 org, V3 dir, const Hit &first, uint32_t 
   }
   return L;
 }
+
+/* ---- photon emission paths: the body of Render::createPhotonMap's thread function,
+ * src/Render.cpp:410-461 ---- */
+struct PhotonRec {
+  V3 pos, wi, power;
+};
+
+/* One pass of the outer `while (k < endIndex)` loop: sample a light point, then bounce.
+ * rng_of(b) is the draw source of bounce b (the light sample draws from rng_of(0) first).
+ * Stores the photons the reference stores in photonMap, at most `room` of them (the
+ * reference's `k < endIndex`); returns their number, or -1 when the scene has no light
+ * (the reference leaves its loop then, :413-415). */
+template <class RngOf>
+int photon_path(const orc_scene *s, RngOf &rng_of, PhotonRec *out, int room, uint64_t *rays) {
+  Hit inter;
+  float pdf = -1.0f;
+  sample_light(s, rng_of(0), inter, pdf);
+  if (inter.prim < 0) return -1;
+  const Mat *im = &s->mats[s->prim_mat[inter.prim]];
+  PhotonRec pre;
+  pre.pos = inter.pos;
+  pre.wi = unit(inter.nrm);
+  pre.power = im->emission;
+  int k = 0, max_deep = 64;
+  for (int b = 0;; b++) {
+    max_deep--;
+    auto &rng = rng_of(b);
+    V3 pre_wo = mat_sample(*im, s->math, pre.wi, unit(inter.nrm), rng);
+    /* Vector3f::norm() is the squared length, compared with a double literal (:427) */
+    if ((double)(pre_wo.x * pre_wo.x + pre_wo.y * pre_wo.y + pre_wo.z * pre_wo.z) < 1e-5) break;
+    pre_wo = unit(pre_wo);
+    if (rays) (*rays)++;
+    Hit next = closest(s, pre.pos, pre_wo, nullptr);
+    if (!next.hit) break;
+    const Mat *nm = &s->mats[s->prim_mat[next.prim]];
+    if (nm->emissive()) break;
+    PhotonRec ph;
+    ph.pos = next.pos;
+    ph.wi = -pre_wo;
+    if (!im->emissive()) {
+      ph.power = mat_eval(*im, pre.wi, pre_wo, unit(inter.nrm)) * pre.power *
+                 dot(unit(inter.nrm), pre_wo) * dot(unit(next.nrm), ph.wi);
+    } else {
+      ph.power = pre.power * dot(unit(inter.nrm), pre_wo) * dot(unit(next.nrm), ph.wi);
+    }
+    if (im->kind == 0) out[k++] = ph; /* stored only when the vertex left is DIFFUSE (:451) */
+    pre = ph;
+    inter = next;
+    im = nm;
+    /* :461 -- the roulette draw is only made when the first two conditions hold */
+    if (!(k < room && max_deep >= 0)) break;
+    if (!(rng() < 0.6f || im->kind != 0)) break;
+  }
+  return k;
+}
+
+/* every bounce of path `path` draws from its own counter stream */
+struct PhotonStreams {
+  uint32_t seed, path;
+  int bounce;
+  VertexStream cur;
+  PhotonStreams(uint32_t se, uint32_t pa) : seed(se), path(pa), bounce(0), cur(se, pa, 0, 0, 1) {}
+  VertexStream &operator()(int b) {
+    if (b != bounce) {
+      cur = VertexStream(seed, path, 0, (uint32_t)b, 1);
+      bounce = b;
+    }
+    return cur;
+  }
+};
+template <class Rng>
+struct OneSource {
+  Rng &r;
+  Rng &operator()(int) { return r; }
+};
 
 struct CameraSetup {
   V3 eye, front, hstep, vstep;
@@ -1140,6 +1216,66 @@ void orc_render(const orc_scene *s, const orc_render_params *p, float *rgb, uint
       for (int t = 0; t < nthreads; t++) stats[k] += tstats[t][k];
     }
   }
+}
+
+int32_t orc_photon_path(const orc_scene *s, uint32_t seed, uint32_t path, int32_t room, float *pos3,
+                        float *wi3, float *power3) {
+  std::vector<PhotonRec> buf(66);
+  PhotonStreams src(seed, path);
+  int k = photon_path(s, src, buf.data(), room < 65 ? room : 65, nullptr);
+  for (int j = 0; j < k; j++) {
+    const V3 v[3] = {buf[j].pos, buf[j].wi, buf[j].power};
+    float *dst[3] = {pos3, wi3, power3};
+    for (int a = 0; a < 3; a++)
+      if (dst[a]) { dst[a][3 * j] = v[a].x; dst[a][3 * j + 1] = v[a].y; dst[a][3 * j + 2] = v[a].z; }
+  }
+  return k;
+}
+
+int64_t orc_create_photon_map(const orc_scene *s, uint32_t seed, int64_t photon_num, float *pos3,
+                              float *wi3, float *power3, uint32_t *paths_used) {
+  std::vector<PhotonRec> buf(66);
+  int64_t k = 0;
+  uint32_t path = 0;
+  int barren = 0;
+  while (k < photon_num) {
+    PhotonStreams src(seed, path);
+    int64_t room = photon_num - k;
+    int got = photon_path(s, src, buf.data(), room < 65 ? (int)room : 65, nullptr);
+    if (got < 0) break;
+    barren = got == 0 ? barren + 1 : 0;
+    if (barren > (1 << 22)) break; /* no path stores anything: the reference would never return */
+    for (int j = 0; j < got; j++, k++) {
+      const V3 v[3] = {buf[j].pos, buf[j].wi, buf[j].power};
+      float *dst[3] = {pos3, wi3, power3};
+      for (int a = 0; a < 3; a++) { dst[a][3 * k] = v[a].x; dst[a][3 * k + 1] = v[a].y; dst[a][3 * k + 2] = v[a].z; }
+    }
+    path++;
+    if (path == 0xffffffffu) break;
+  }
+  if (paths_used) *paths_used = path;
+  return k;
+}
+
+int32_t orc_create_photon_map_u(const orc_scene *s, const float *u, int n_u, int32_t photon_num,
+                                float *pos3, float *wi3, float *power3, int32_t *used) {
+  ArrayRng rng{u, n_u, 0};
+  OneSource<ArrayRng> src{rng};
+  std::vector<PhotonRec> buf(66);
+  int32_t k = 0;
+  while (k < photon_num) {
+    int room = photon_num - k;
+    int got = photon_path(s, src, buf.data(), room < 65 ? room : 65, nullptr);
+    if (got < 0) break;
+    for (int j = 0; j < got; j++, k++) {
+      const V3 v[3] = {buf[j].pos, buf[j].wi, buf[j].power};
+      float *dst[3] = {pos3, wi3, power3};
+      for (int a = 0; a < 3; a++) { dst[a][3 * k] = v[a].x; dst[a][3 * k + 1] = v[a].y; dst[a][3 * k + 2] = v[a].z; }
+    }
+    if (rng.used > n_u + 4096) break; /* ran far past the supplied draws */
+  }
+  if (used) *used = rng.used;
+  return k;
 }
 
 unsigned char orc_tonemap(float v) {

@@ -151,6 +151,23 @@ void orc_render(const orc_scene *s, const orc_render_params *p, float *rgb,
 /* primary ray for pixel (i,j), src/Render.cpp:639-655 */
 void orc_primary_ray(const orc_scene *s, int W, int H, int i, int j,
                      float org[3], float dir[3]);
+/* ---- photon emission: Render::createPhotonMap, src/Render.cpp:405-481 ----
+ * The reference fills photonMap[k] sequentially per thread from the shared mt19937.
+ * Here emission path number `path` draws bounce b's uniforms from the counter stream
+ * (pixel = path, sample = 0, bounce = b) under key (seed, 1), and the map is the first
+ * photon_num photons of paths 0, 1, 2, ... in that order -- what one reference thread
+ * produces from such draws. */
+/* photons path `path` stores (at most `room`, at most 65); returns their number, -1
+ * without lights.  Output arrays hold 65 x 3 floats (may be NULL). */
+int32_t orc_photon_path(const orc_scene *s, uint32_t seed, uint32_t path, int32_t room, float *pos3,
+                        float *wi3, float *power3);
+int64_t orc_create_photon_map(const orc_scene *s, uint32_t seed, int64_t photon_num, float *pos3,
+                              float *wi3, float *power3, uint32_t *paths_used);
+/* the same drawing from an explicit array of uniforms in the reference's draw order
+ * (one thread, i.e. photon_num < 16 in the reference); *used = draws consumed */
+int32_t orc_create_photon_map_u(const orc_scene *s, const float *u, int n_u, int32_t photon_num,
+                                float *pos3, float *wi3, float *power3, int32_t *used);
+
 /* tone map one linear value like Render::saveFile, src/Render.cpp:10-12 */
 unsigned char orc_tonemap(float v);
 

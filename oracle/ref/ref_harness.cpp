@@ -287,6 +287,28 @@ void ref_path_trace(void *h, const float org[3], const float dir[3], uint32_t se
   rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 
+/* Render::createPhotonMap after seeding.  photon_num must be below 16: the reference then
+ * runs its thread function once over [0, photon_num) (src/Render.cpp:467-470), so the draws
+ * are reproducible; from 16 on, 16 threads race on the one generator.  Returns the number
+ * of map entries that were filled. */
+int ref_create_photon_map(void *h, uint32_t seed, unsigned photon_num, float *pos3, float *wi3,
+                          float *power3) {
+  RefScene *r = (RefScene *)h;
+  if (photon_num >= 16) return -1;
+  ref_rng_seed(seed);
+  std::vector<Photon *> map(photon_num, nullptr);
+  r->render.createPhotonMap(*r->scene, &map, photon_num);
+  int k = 0;
+  for (unsigned i = 0; i < photon_num; i++) {
+    if (!map[i]) continue;
+    const Vector3f v[3] = {map[i]->pos, map[i]->wi, map[i]->power};
+    float *dst[3] = {pos3, wi3, power3};
+    for (int a = 0; a < 3; a++) { dst[a][3 * k] = v[a].x; dst[a][3 * k + 1] = v[a].y; dst[a][3 * k + 2] = v[a].z; }
+    k++;
+  }
+  return k;
+}
+
 /* Render::renderPathTracing (16 threads, unsynchronised generator, writes
  * <file>.ppm); copies the private float buffer out.  Returns 0 on success. */
 int ref_render(void *h, unsigned W, unsigned H, unsigned spp, const char *file, float *rgb) {

@@ -57,7 +57,8 @@ ABI_SYMBOLS = [
     "rtr_last_error", "rtr_device_count", "rtr_scene_create", "rtr_scene_destroy",
     "rtr_trace_closest", "rtr_trace_closest_device", "rtr_material_eval", "rtr_material_sample",
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
-    "rtr_partition_columns", "rtr_check_connectable",
+    "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
+    "rtr_create_photon_map_device",
 ]
 
 _hip = None
@@ -80,6 +81,10 @@ def hip_lib():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
         L.rtr_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.rtr_create_photon_map.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _fp, _fp, _fp,
+                                            C.POINTER(C.c_uint64), _up]
+        L.rtr_create_photon_map_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), _up]
         L.rtr_material_eval.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp, _fp]
         L.rtr_material_sample.argtypes = [C.c_void_p, _ip, _fp, _fp, _fp, C.c_size_t, _fp]
         L.rtr_sample_light.argtypes = [C.c_void_p, _fp, C.c_int32, C.c_size_t, _fp, _fp, _fp, _ip,
@@ -121,6 +126,8 @@ def host_lib():
         L.rtrh_material_id.argtypes = [C.c_void_p, C.c_int]
         L.rtrh_intersect.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
         L.rtrh_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, C.POINTER(C.c_uint8)]
+        L.rtrh_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp, _fp]
+        L.rtrh_create_photon_map.restype = C.c_int64
         L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
                                   C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
         _host = L
@@ -286,6 +293,23 @@ class HostScene:
         _check(hip_lib().rtr_trace_closest(self.device_scene(), _f(org), _f(dirs), n, _i(prim),
                                            _f(t), _f(pos), _f(nrm)), "rtr_trace_closest")
         return prim, t, pos, nrm
+
+    def create_photon_map(self, n, seed=0, via_host_api=False):
+        """Render::createPhotonMap: (pos, wi, power, emission paths used); each array k x 3
+        with k = n, or 0 for a scene without lights.  via_host_api: through the C++ mirror
+        (Render::createPhotonMap) instead of the C ABI call directly."""
+        out = [np.zeros((max(n, 1), 3), f32) for _ in range(3)]
+        if via_host_api:
+            k = self.L.rtrh_create_photon_map(self.h, seed, n, _f(out[0]), _f(out[1]), _f(out[2]))
+            if k < 0:
+                self._herr("create_photon_map")
+            return [a[:k] for a in out] + [None]
+        stored = C.c_uint64(0)
+        used = np.zeros(1, np.uint32)
+        _check(hip_lib().rtr_create_photon_map(self.device_scene(), n, seed, _f(out[0]), _f(out[1]),
+                                               _f(out[2]), C.byref(stored), _u(used)),
+               "rtr_create_photon_map")
+        return [a[:stored.value] for a in out] + [int(used[0])]
 
     def check_connectable(self, a, b, via_host_api=False):
         """Scene::checkConnectable for many pairs: uint8 array, 1 where b is reached from a.

@@ -100,6 +100,10 @@ struct rtr_scene {
   // different streams do not share one
   DevBuf<unsigned long long> trace_next;
   unsigned trace_next_turn = 0;
+  // photon emission: per-path counts of a batch, per-workgroup sums and offsets,
+  // {photons in the batch, -}, number of paths the map took
+  DevBuf<uint32_t> ph_counts, ph_paths_used;
+  DevBuf<unsigned long long> ph_sums, ph_offs, ph_total;
   Workspace ws;
   // scratch for the host-pointer entry points
   DevBuf<float> io_f[5];
@@ -542,6 +546,8 @@ void rtr_scene_destroy(rtr_scene *s) {
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();
   s->trace_next.release();
+  s->ph_counts.release(); s->ph_paths_used.release(); s->ph_sums.release(); s->ph_offs.release();
+  s->ph_total.release();
   for (auto &b : s->io_f) b.release();
   for (auto &b : s->io_i) b.release();
   if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
@@ -722,6 +728,90 @@ int rtr_check_connectable(rtr_scene *s, const float *a_xyz, const float *b_xyz, 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(connected, out, count, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTR_OK;
+}
+
+int rtr_create_photon_map_device(rtr_scene *s, uint64_t photon_num, uint32_t seed, float *d_pos,
+                                 float *d_wi, float *d_power, uint64_t *n_stored,
+                                 uint32_t *paths_used) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n_stored) *n_stored = 0;
+  if (paths_used) *paths_used = 0;
+  if (photon_num == 0) return RTR_OK;
+  if (!d_pos || !d_wi || !d_power) return fail(RTR_ERR_INVALID, "null photon array");
+  DeviceGuard guard(s->device);
+  if (s->dl.n_lights == 0) return RTR_OK;  // the reference leaves the map empty (:413-415)
+  hipStream_t st = s->stream;
+  HIP_TRY(s->ph_total.reserve(1));
+  HIP_TRY(s->ph_paths_used.reserve(1));
+  HIP_TRY(hipMemsetAsync(s->ph_paths_used.ptr, 0, sizeof(uint32_t), st));
+  uint64_t filled = 0, paths = 0;
+  int barren = 0;
+  while (filled < photon_num) {
+    // batch: enough paths for what is missing at the yield seen so far (first guess: two
+    // photons per path), at least 4 Ki, at most 4 Mi
+    const double yield = paths ? std::max((double)filled / (double)paths, 0.05) : 2.0;
+    uint64_t want = (uint64_t)((double)(photon_num - filled) / yield * 1.05) + 1024;
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 4096), (uint64_t)1 << 22);
+    const uint32_t n_paths = (uint32_t)((want + kBlock - 1) / kBlock * kBlock);
+    if (paths + n_paths > 0xffffffffull) return fail(RTR_ERR_INVALID, "photon map needs too many emission paths");
+    const unsigned nb = n_paths / kBlock;
+    HIP_TRY(s->ph_counts.reserve(n_paths));
+    HIP_TRY(s->ph_sums.reserve(nb));
+    HIP_TRY(s->ph_offs.reserve(nb));
+    PhotonArgs a{seed, (uint32_t)paths, n_paths, filled, photon_num};
+    if (s->lds_geometry)
+      hipLaunchKernelGGL((k_photon_paths<true, false>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
+                         d_power, s->ph_paths_used.ptr);
+    else
+      hipLaunchKernelGGL((k_photon_paths<false, false>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
+                         d_power, s->ph_paths_used.ptr);
+    hipLaunchKernelGGL(k_photon_scan, dim3(1), dim3(kBlock), 0, st, s->ph_sums.ptr, s->ph_offs.ptr, nb,
+                       s->ph_total.ptr);
+    if (s->lds_geometry)
+      hipLaunchKernelGGL((k_photon_paths<true, true>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
+                         d_power, s->ph_paths_used.ptr);
+    else
+      hipLaunchKernelGGL((k_photon_paths<false, true>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
+                         d_power, s->ph_paths_used.ptr);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, s->ph_total.ptr, sizeof(total), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    filled += total;
+    paths += n_paths;
+    barren = total == 0 ? barren + 1 : 0;
+    // lights exist but no path ever stores a photon: the reference would loop for ever
+    if (barren >= 4) return fail(RTR_ERR_INVALID, "no emission path stores a photon in this scene");
+  }
+  uint32_t used = 0;
+  HIP_TRY(hipMemcpy(&used, s->ph_paths_used.ptr, sizeof(used), hipMemcpyDeviceToHost));
+  if (n_stored) *n_stored = std::min<uint64_t>(filled, photon_num);
+  if (paths_used) *paths_used = used;
+  return RTR_OK;
+}
+
+int rtr_create_photon_map(rtr_scene *s, uint64_t photon_num, uint32_t seed, float *pos_xyz,
+                          float *wi_xyz, float *power_xyz, uint64_t *n_stored, uint32_t *paths_used) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n_stored) *n_stored = 0;
+  if (paths_used) *paths_used = 0;
+  if (photon_num == 0) return RTR_OK;
+  if (!pos_xyz || !wi_xyz || !power_xyz) return fail(RTR_ERR_INVALID, "null photon array");
+  DeviceGuard guard(s->device);
+  for (int k = 0; k < 3; k++) HIP_TRY(s->io_f[k].reserve(3 * photon_num));
+  uint64_t stored = 0;
+  int rc = rtr_create_photon_map_device(s, photon_num, seed, s->io_f[0].ptr, s->io_f[1].ptr,
+                                        s->io_f[2].ptr, &stored, paths_used);
+  if (rc) return rc;
+  float *dst[3] = {pos_xyz, wi_xyz, power_xyz};
+  for (int k = 0; k < 3; k++)
+    if (stored) HIP_TRY(hipMemcpy(dst[k], s->io_f[k].ptr, 12 * stored, hipMemcpyDeviceToHost));
+  if (n_stored) *n_stored = stored;
   return RTR_OK;
 }
 

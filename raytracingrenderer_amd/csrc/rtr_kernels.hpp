@@ -1009,6 +1009,161 @@ k_resolve(RenderArgs a, const float4 *__restrict__ partial, float *__restrict__ 
   rgb[3 * (size_t)lp + 2] = c.z;
 }
 
+// ---- photon emission: the thread function of Render::createPhotonMap, src/Render.cpp:407-463 ----
+// The reference fills photonMap[k] one emission path after the other from the shared
+// generator.  Here path number p draws bounce b's uniforms from the counter stream
+// (pixel = p, sample = 0, bounce = b) under key (seed, 1), so paths are independent: one
+// lane runs one path.  The map is the first photon_num photons of paths 0, 1, 2, ... in
+// path order, which takes two passes over a batch of paths: the first counts what each
+// path stores, a scan turns counts into positions, the second runs the same paths again
+// and writes.  (A path that the reference would cut short because the map filled up
+// mid-path is run to its end here; the photons past the end are not written.)
+struct PhotonArgs {
+  uint32_t seed, first_path, n_paths;
+  unsigned long long base;   // photons stored by earlier batches
+  unsigned long long limit;  // photon_num
+};
+
+template <bool kLds, bool kWrite>
+__global__ void __launch_bounds__(kBlock)
+k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
+               uint32_t *__restrict__ counts, unsigned long long *__restrict__ block_sums,
+               const unsigned long long *__restrict__ block_offs, float *__restrict__ pos3,
+               float *__restrict__ wi3, float *__restrict__ power3,
+               unsigned int *__restrict__ paths_used) {
+  __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
+  __shared__ LdsScene lds;
+  __shared__ unsigned s_cnt[kBlock];
+  __shared__ unsigned s_total;
+  if (kLds) stage_scene(sc, lds, threadIdx.x, kBlock);
+  if (threadIdx.x == 0) s_total = 0;
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = p < a.n_paths;
+  const uint32_t path = a.first_path + p;
+  unsigned long long out = 0;
+  if (kWrite) s_cnt[threadIdx.x] = valid ? counts[p] : 0u;
+  __syncthreads();
+  if (kWrite) {
+    unsigned before = 0;
+    for (unsigned t = 0; t < threadIdx.x; t++) before += s_cnt[t];
+    out = a.base + block_offs[blockIdx.x] + before;
+    // the path that stores photon number `limit` is the last one the reference starts
+    if (valid && out < a.limit && out + s_cnt[threadIdx.x] >= a.limit) *paths_used = path + 1u;
+  }
+  const GlobalTables T{sc, L, mats};
+  typename WaveLds<kLds>::type &ws = wsh[threadIdx.x >> 6];
+
+  VertexStream rng(a.seed, path, 0u, 0u, 1u);
+  bool active = valid;
+  LightSample ls;
+  ls.leaf = -1;
+  ls.light = 0;
+  ls.pos = mk(0, 0, 0);
+  ls.nrm = mk(0, 0, 1);
+  if (active) {
+    sample_light(T, rng, ls);
+    if (ls.leaf < 0) active = false;  // no light: the reference leaves its loop (:413-415)
+  }
+  V3 ppos = ls.pos, N = unit(ls.nrm), pwi = N, ppow = mk(0, 0, 0);
+  DeviceMaterial im = mats[0];
+  if (active) {
+    const HitRec lh{0.0f, 0.0f, 0.0f, ls.leaf};
+    im = mats[sc.prim_material[hit_prim(sc, lh)]];
+    ppow = xyz(im.e_kind);
+  }
+  uint32_t k = 0, bounce = 0;
+  int max_deep = 64;
+  while (__ballot(active)) {
+    V3 wo = mk(0, 0, 1);
+    bool shoot = false;
+    if (active) {
+      max_deep--;
+      if (bounce != 0) rng = VertexStream(a.seed, path, 0u, bounce, 1u);
+      if (mat_kind(im) == 1) {
+        wo = mat_mirror(pwi, N);
+      } else {
+        const float u1 = rng.next();
+        const float u2 = rng.next();
+        wo = mat_sample_uv(N, u1, u2);
+      }
+      // Vector3f::norm() is the squared length, compared with a double literal (:427)
+      if ((double)(wo.x * wo.x + wo.y * wo.y + wo.z * wo.z) < 1e-5) {
+        active = false;
+      } else {
+        wo = unit(wo);
+        shoot = true;
+      }
+    }
+    const V3 wn = unit(wo);
+    const HitRec h = trace_any<kLds>(sc, lds, shoot, ppos, wo, wn, ws);
+    if (shoot) {
+      bool go_on = false;
+      if (h.leaf >= 0) {
+        const DeviceMaterial nm = mats[sc.prim_material[hit_prim(sc, h)]];
+        if (!mat_emissive(nm)) {
+          V3 hp, hn;
+          hit_point(sc, h, ppos, wn, hp, hn);
+          const V3 nw = -wo;
+          const V3 un = unit(hn);
+          V3 npow;
+          if (!mat_emissive(im)) npow = mat_eval(im, pwi, wo, N) * ppow * dot(N, wo) * dot(un, nw);
+          else npow = ppow * dot(N, wo) * dot(un, nw);
+          if (mat_kind(im) == 0) {  // stored only when the vertex left is DIFFUSE (:451)
+            if (kWrite && out + k < a.limit) {
+              const unsigned long long q = 3ull * (out + k);
+              pos3[q] = hp.x; pos3[q + 1] = hp.y; pos3[q + 2] = hp.z;
+              wi3[q] = nw.x; wi3[q + 1] = nw.y; wi3[q + 2] = nw.z;
+              power3[q] = npow.x; power3[q + 1] = npow.y; power3[q + 2] = npow.z;
+            }
+            k++;
+          }
+          ppos = hp;
+          pwi = nw;
+          ppow = npow;
+          N = un;
+          im = nm;
+          go_on = true;
+        }
+      }
+      if (!go_on) {
+        active = false;
+      } else if (max_deep < 0) {  // :461; `k < endIndex` is the write limit above
+        active = false;
+      } else {
+        const float u = rng.next();
+        if (!(u < 0.6f || mat_kind(im) != 0)) active = false;
+        bounce++;
+      }
+    }
+  }
+  if (!kWrite) {
+    if (valid) counts[p] = k;
+    if (k) atomicAdd(&s_total, k);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_total;
+  }
+}
+
+// exclusive scan of the per-workgroup photon counts of a batch (one workgroup)
+__global__ void __launch_bounds__(kBlock)
+k_photon_scan(const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ block_offs,
+              unsigned n_blocks, unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long s_part[kBlock];
+  const unsigned per = (n_blocks + kBlock - 1) / kBlock;
+  const unsigned b0 = threadIdx.x * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  unsigned long long sum = 0;
+  for (unsigned b = b0; b < b1; b++) sum += block_sums[b];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  unsigned long long before = 0;
+  for (unsigned t = 0; t < threadIdx.x; t++) before += s_part[t];
+  for (unsigned b = b0; b < b1; b++) {
+    block_offs[b] = before;
+    before += block_sums[b];
+  }
+  if (threadIdx.x == kBlock - 1) *total = before;
+}
+
 // ---- unit-level entry points used by the parity tests ----
 struct ArrayStream {
   const float *u;

@@ -100,17 +100,19 @@ RTR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 RTR_DEV float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }
 
 // Uniform number `dim` of path vertex `bounce` of sample `sample` of pixel
-// `pixel`: word dim&3 of block (pixel, sample, bounce, dim>>2), key (seed, 0).
+// `pixel`: word dim&3 of block (pixel, sample, bounce, dim>>2), key (seed, key1).
+// key1 = 0: path tracing; 1: photon emission paths (pixel = path number, sample = 0).
 struct VertexStream {
   uint32_t seed, pixel, sample, bounce, dim;
   uint32_t w[4];
   int block;
-  RTR_DEV VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo)
-      : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), block(-1) {}
+  uint32_t key1;
+  RTR_DEV VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo, uint32_t k1 = 0u)
+      : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), block(-1), key1(k1) {}
   RTR_DEV float next() {
     int b = (int)(dim >> 2);
     if (b != block) {
-      philox4x32_10(pixel, sample, bounce, (uint32_t)b, seed, 0u, w);
+      philox4x32_10(pixel, sample, bounce, (uint32_t)b, seed, key1, w);
       block = b;
     }
     uint32_t d = dim & 3u;

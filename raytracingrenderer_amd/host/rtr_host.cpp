@@ -547,6 +547,24 @@ void Render::render(Scene &scene, const unsigned int &imageWidth, const unsigned
   renderPathTracing(scene, imageWidth, imageHeight, spp, fileName);
 }
 
+void Render::createPhotonMap(Scene &scene, std::vector<Photon *> *photonMap, unsigned int photonNum) {
+  if (!photonMap) throw std::invalid_argument("Render::createPhotonMap: null photon map");
+  photonMap->assign(photonNum, nullptr);
+  if (photonNum == 0) return;
+  std::vector<float> pos(3 * (size_t)photonNum), wi(pos.size()), power(pos.size());
+  uint64_t stored = 0;
+  rtr_check(rtr_create_photon_map(scene.deviceScene(), photonNum, options.seed, pos.data(), wi.data(),
+                                  power.data(), &stored, nullptr),
+            "rtr_create_photon_map");
+  for (uint64_t k = 0; k < stored; k++) {
+    Photon *ph = new Photon();
+    ph->pos = Vector3f(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
+    ph->wi = Vector3f(wi[3 * k], wi[3 * k + 1], wi[3 * k + 2]);
+    ph->power = Vector3f(power[3 * k], power[3 * k + 1], power[3 * k + 2]);
+    (*photonMap)[k] = ph;
+  }
+}
+
 // ---------------- C facade for language bindings (tests drive it with ctypes) ----------------
 namespace {
 struct HostScene {
@@ -722,6 +740,30 @@ int rtrh_intersect(void *hs, const float *org, const float *dir, int64_t n, int3
 int rtrh_check_connectable(void *hs, const float *a, const float *b, int64_t n, uint8_t *connected) {
   HostScene *h = (HostScene *)hs;
   return guarded([&] { h->scene->checkConnectableBatch(a, b, (size_t)n, connected); });
+}
+
+// Render::createPhotonMap through the C++ mirror; arrays hold n rows; returns rows filled
+int64_t rtrh_create_photon_map(void *hs, uint32_t seed, uint32_t n, float *pos, float *wi, float *power) {
+  HostScene *h = (HostScene *)hs;
+  int64_t filled = 0;
+  int rc = guarded([&] {
+    h->render.options.seed = seed;
+    std::vector<Photon *> map;
+    h->render.createPhotonMap(*h->scene, &map, n);
+    for (Photon *ph : map) {
+      if (!ph) continue;
+      const Vector3f v[3] = {ph->pos, ph->wi, ph->power};
+      float *dst[3] = {pos, wi, power};
+      for (int a = 0; a < 3; a++) {
+        dst[a][3 * filled] = v[a].x;
+        dst[a][3 * filled + 1] = v[a].y;
+        dst[a][3 * filled + 2] = v[a].z;
+      }
+      filled++;
+      delete ph;
+    }
+  });
+  return rc ? -1 : filled;
 }
 
 // Render::renderPathTracing; file may be NULL/"" (no PPM).  rgb gets the buffer.

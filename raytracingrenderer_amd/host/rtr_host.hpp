@@ -257,6 +257,13 @@ struct RenderOptions {  // what the reference hard-codes, see rtr_render_params
   int mode = 0, streams = 0;  // rtr_render_params::mode / ::streams
 };
 
+// ---- include/Photon.h ----
+struct Photon {
+  Vector3f pos;
+  Vector3f wi;
+  Vector3f power;
+};
+
 class Render {
   std::vector<Vector3f> *buffer = nullptr;
   rtr_stats lastStats{};
@@ -272,6 +279,12 @@ class Render {
                          std::string fileName);
   void render(Scene &scene, const unsigned int &imageWidth, const unsigned int &imageHeight,
               const unsigned int &spp, std::string fileName, RenderType type);
+  // Render::createPhotonMap, src/Render.cpp:405-481: fills photonMap (resized to
+  // photonNum) with newly allocated photons the caller owns, like the reference; entries
+  // stay null when the scene has no light.  Draws come from options.seed (see
+  // rtr_create_photon_map).  Public here; the reference keeps it private to its
+  // photon-mapping integrator.
+  void createPhotonMap(Scene &scene, std::vector<Photon *> *photonMap, unsigned int photonNum);
   const std::vector<Vector3f> &getBuffer() const { return *buffer; }
   const rtr_stats &getStats() const { return lastStats; }
   // Render::saveFile, src/Render.cpp:3-21 (public here so tools can reuse it)

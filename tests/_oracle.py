@@ -215,6 +215,10 @@ class Oracle(_Backend):
         L.orc_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
         L.orc_tonemap.argtypes = [C.c_float]
         L.orc_tonemap.restype = C.c_ubyte
+        L.orc_photon_path.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp, _fp]
+        L.orc_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, _fp, _fp, _fp, _up]
+        L.orc_create_photon_map.restype = C.c_int64
+        L.orc_create_photon_map_u.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int32, _fp, _fp, _fp, _ip]
 
     def default_scene(self):
         ids = {m[0]: i for i, m in enumerate(default_scene_spec()["materials"])}
@@ -247,6 +251,31 @@ class Oracle(_Backend):
         used = np.zeros(1, np.int32)
         self.lib.orc_path_trace_u(scene.h, _f(org), _f(d), _f(u), len(u), _f(rgb), _i(used))
         return rgb, int(used[0])
+
+    def photon_path(self, scene, seed, path, room=65):
+        """Photons emission path `path` stores: (pos, wi, power), each k x 3; None without lights."""
+        out = [np.zeros((65, 3), f32) for _ in range(3)]
+        k = self.lib.orc_photon_path(scene.h, seed, path, room, _f(out[0]), _f(out[1]), _f(out[2]))
+        if k < 0:
+            return None
+        return [a[:k] for a in out]
+
+    def create_photon_map(self, scene, n, seed=0):
+        """Render::createPhotonMap with the counter streams: (pos, wi, power, paths used)."""
+        out = [np.zeros((max(n, 1), 3), f32) for _ in range(3)]
+        used = np.zeros(1, np.uint32)
+        k = self.lib.orc_create_photon_map(scene.h, seed, n, _f(out[0]), _f(out[1]), _f(out[2]),
+                                           used.ctypes.data_as(_up))
+        return [a[:k] for a in out] + [int(used[0])]
+
+    def create_photon_map_u(self, scene, u, n):
+        """The same from explicit draws in the reference's order: (pos, wi, power, draws used)."""
+        u = np.ascontiguousarray(u, f32)
+        out = [np.zeros((max(n, 1), 3), f32) for _ in range(3)]
+        used = np.zeros(1, np.int32)
+        k = self.lib.orc_create_photon_map_u(scene.h, _f(u), len(u), n, _f(out[0]), _f(out[1]),
+                                             _f(out[2]), _i(used))
+        return [a[:k] for a in out] + [int(used[0])]
 
     def philox(self, ctr, key):
         c = np.array(ctr, np.uint32)
@@ -300,6 +329,7 @@ class Ref(_Backend):
         L.ref_sample_light.argtypes = [C.c_void_p, C.c_uint32, _fp, _fp, _fp, _ip]
         L.ref_path_trace.argtypes = [C.c_void_p, _fp, _fp, C.c_uint32, _fp]
         L.ref_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, _fp]
+        L.ref_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint, _fp, _fp, _fp]
 
     def default_scene(self):
         return self.build_scene(default_scene_spec())
@@ -331,6 +361,13 @@ class Ref(_Backend):
         rgb = np.zeros(3, f32)
         self.lib.ref_path_trace(scene.h, _f(org), _f(d), seed, _f(rgb))
         return rgb
+
+    def create_photon_map(self, scene, n, seed):
+        """Render::createPhotonMap (n < 16: one thread, reproducible): (pos, wi, power)."""
+        out = [np.zeros((max(n, 1), 3), f32) for _ in range(3)]
+        k = self.lib.ref_create_photon_map(scene.h, seed, n, _f(out[0]), _f(out[1]), _f(out[2]))
+        assert k >= 0
+        return [a[:k] for a in out]
 
     def render(self, scene, W, H, spp, file="/tmp/ref_render"):
         rgb = np.zeros((W * H, 3), f32)

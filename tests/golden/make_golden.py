@@ -49,14 +49,42 @@ def connectable(sr):
     print("connectable pairs:", len(a), "connected:", int(got.sum()))
 
 
+def photon_maps(R):
+    """Render::createPhotonMap (src/Render.cpp:405-481) of the reference, 15 photons per call
+    (below 16 the reference runs one thread, so its draws can be replayed), with the
+    generator's draws after the same seeding, on the default scene and on the scene with a
+    second sphere light and an emissive mesh."""
+    out = {}
+    for name, spec in (("default", default_scene_spec()), ("lights", multi_light_spec())):
+        sr = R.build_scene(spec)
+        seeds = np.arange(100, 160, dtype=np.uint32)
+        draws, pos, wi, power = [], [], [], []
+        for sd in seeds:
+            p = R.create_photon_map(sr, 15, int(sd))
+            assert len(p[0]) == 15
+            draws.append(R.draws(int(sd), 320))
+            pos.append(p[0]); wi.append(p[1]); power.append(p[2])
+        out[name + "_seeds"] = seeds
+        out[name + "_draws"] = np.array(draws, f32)
+        out[name + "_pos"] = np.array(pos, f32)
+        out[name + "_wi"] = np.array(wi, f32)
+        out[name + "_power"] = np.array(power, f32)
+    np.savez_compressed(os.path.join(HERE, "photons.npz"), **out)
+    print("photon maps:", {k: v.shape for k, v in out.items()})
+
+
 def main():
     R = Ref()
     O = Oracle()  # only used to generate primary-ray INPUTS (camera set-up)
     sr = R.default_scene()
     so = O.default_scene()
+    if "--only-photons" in sys.argv:
+        photon_maps(R)
+        return
     connectable(sr)
     if "--only-connectable" in sys.argv:
         return
+    photon_maps(R)
 
     lo, hi, child, prim = sr.flatten()
     np.savez_compressed(os.path.join(HERE, "bvh_default.npz"), bmin=lo, bmax=hi, child=child,

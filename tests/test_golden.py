@@ -110,6 +110,47 @@ def test_check_connectable_golden(osc):
     assert 2000 < g["connected"].sum() < len(g["a"]) - 2000
 
 
+def test_photon_map_golden(osc):
+    """Render::createPhotonMap of the reference (15 photons per call, one thread) against
+    the restatement fed with the same generator draws: positions, directions, powers."""
+    O, so = osc
+    g = _load("photons.npz")
+    scenes = {"default": so, "lights": O.build_scene(_multi_light_spec())}
+    for name, sc in scenes.items():
+        n_draws = []
+        for k in range(len(g[name + "_seeds"])):
+            pos, wi, power, used = O.create_photon_map_u(sc, g[name + "_draws"][k], 15)
+            assert used <= g[name + "_draws"].shape[1]
+            n_draws.append(used)
+            assert _rays.same_bits(pos, g[name + "_pos"][k]).all(), (name, k)
+            assert _rays.same_bits(wi, g[name + "_wi"][k]).all(), (name, k)
+            assert _rays.same_bits(power, g[name + "_power"][k]).all(), (name, k)
+        assert max(n_draws) > min(n_draws)
+
+
+def test_photon_map_is_the_concatenation_of_its_paths(osc):
+    """The counter-stream form: the map is the first n photons of paths 0, 1, 2, ... (the
+    last path cut where the map is full), and a path's draws do not depend on the others."""
+    O, so = osc
+    n = 700
+    pos, wi, power, used = O.create_photon_map(so, n, seed=5)
+    assert len(pos) == n
+    cat = [[], [], []]
+    for path in range(used):
+        ph = O.photon_path(so, 5, path)
+        for a, b in zip(cat, ph):
+            a.append(b)
+    cat = [np.concatenate(a)[:n] for a in cat]
+    for a, b in zip((pos, wi, power), cat):
+        assert _rays.same_bits(a, b).all()
+    assert sum(len(O.photon_path(so, 5, p)[0]) for p in range(used - 1)) < n
+    # photons lie on surfaces of the box, arrive from outside the surface, carry positive power
+    assert (power >= 0).all() and power.max() > 1
+    assert np.allclose(np.linalg.norm(wi, axis=1), 1, atol=1e-5)
+    other = O.create_photon_map(so, n, seed=6)[0]
+    assert not np.array_equal(other, pos)
+
+
 def test_philox_known_answers(osc):
     """Philox4x32-10 known-answer vectors of the Random123 distribution."""
     O, _ = osc
@@ -201,6 +242,37 @@ def test_gpu_check_connectable_golden(gsc):
     assert np.array_equal(sg.check_connectable(g["a"], g["b"]), g["connected"])
     assert np.array_equal(sg.check_connectable(g["a"][:500], g["b"][:500], via_host_api=True),
                           g["connected"][:500])
+
+
+@pytest.mark.gpu
+def test_gpu_photon_map(gsc):
+    """rtr_create_photon_map against the restatement with the same counter streams, bit for
+    bit: default scene at several sizes (below and above one batch of paths), through the
+    C++ mirror, and the scene with three lights, one of them an emissive mesh."""
+    rt, sg = gsc
+    O = Oracle()
+    so = O.default_scene()
+    O.set_math(so, portable=True)
+    for n, seed in ((1, 0), (15, 1), (1000, 2), (60000, 3)):
+        want = O.create_photon_map(so, n, seed)
+        got = sg.create_photon_map(n, seed)
+        assert got[3] == want[3], (n, got[3], want[3])
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and _rays.same_bits(a, b).all(), n
+    got = sg.create_photon_map(500, 2, via_host_api=True)
+    want = O.create_photon_map(so, 500, 2)
+    for a, b in zip(got[:3], want[:3]):
+        assert a.shape == b.shape and _rays.same_bits(a, b).all()
+    spec = _multi_light_spec()
+    so2 = O.build_scene(spec)
+    O.set_math(so2, portable=True)
+    sg2 = rt.HostScene.from_spec(spec)
+    want = O.create_photon_map(so2, 20000, 4)
+    got = sg2.create_photon_map(20000, 4)
+    assert got[3] == want[3]
+    for a, b in zip(got[:3], want[:3]):
+        assert a.shape == b.shape and _rays.same_bits(a, b).all()
+    assert len(sg.create_photon_map(0)[0]) == 0
 
 
 @pytest.mark.gpu

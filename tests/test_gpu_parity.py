@@ -178,6 +178,27 @@ def test_degenerate_triangles_in_a_large_scene(rt):
     assert np.isnan(want[1][want[0] >= 0]).any() or np.isinf(want[1][want[0] >= 0]).any()
 
 
+def test_photon_map_large_scene_and_no_lights(rt):
+    """Render::createPhotonMap where traversal walks a tree in memory, on the scene whose
+    spheres are mirrors and microfacet (photons pass through non-diffuse vertices without
+    being stored), and on a scene without lights (the reference leaves its map empty)."""
+    O = Oracle()
+    for spec, n in ((_random_scene_spec(9), 30000), (_rays.heightfield_spec(40), 8000)):
+        so = O.build_scene(spec)
+        O.set_math(so, portable=True)
+        sg = rt.HostScene.from_spec(spec)
+        want = O.create_photon_map(so, n, 11)
+        got = sg.create_photon_map(n, 11)
+        assert got[3] == want[3]
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and _rays.same_bits(a, b).all()
+    spec = default_scene_spec()
+    spec["objects"] = [ob for ob in spec["objects"] if ob[1] != "light"]
+    sg = rt.HostScene.from_spec(spec)
+    got = sg.create_photon_map(100, 1)
+    assert len(got[0]) == 0 and got[3] == 0
+
+
 def test_check_connectable(rt, scenes):
     """Scene::checkConnectable on the default scene (all-leaves traversal) and on a scene
     with thousands of primitives (tree walk): same booleans as the checker."""

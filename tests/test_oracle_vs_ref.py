@@ -234,6 +234,42 @@ def test_path_trace_variant_scene(both):
         assert _rays.same_bits(got, ref).all(), (k, got, ref)
 
 
+def test_photon_map_replays_reference_draws(both):
+    """Render::createPhotonMap with 15 photons (below 16 the reference runs one thread) on
+    the default scene, on its specular / microfacet variant and with three lights: the
+    restatement fed with the generator's draws gives the same photons bit for bit."""
+    O, R, so, sr = both
+    variant = default_scene_spec()
+    objs = []
+    for ob in variant["objects"]:
+        if ob[0] == "sphere" and ob[1] in ("red", "blue"):
+            ob = ("sphere", "spec", ob[2], ob[3])
+        if ob[0] == "sphere" and ob[1] == "green":
+            ob = ("sphere", "micro", ob[2], ob[3])
+        objs.append(ob)
+    variant["objects"] = objs
+    lights = default_scene_spec()
+    plate = np.array([[224, 20, -288], [288, 20, -288], [224, 20, -224], [288, 20, -224]], f32)
+    lights["objects"] = [("sphere", "light", (100, 300, -200), 15)] + lights["objects"] + \
+                        [("mesh", "light", plate, [0, 1, 2, 3, 2, 1])]
+    cases = [(so, sr, 250)] + [(O.build_scene(sp), R.build_scene(sp), 120) for sp in (variant, lights)]
+    for a, b, n_seeds in cases:
+        total = 0
+        for seed in range(n_seeds):
+            want = R.create_photon_map(b, 15, seed)
+            got = O.create_photon_map_u(a, R.draws(seed, 2000), 15)
+            assert got[3] < 2000
+            for x, y in zip(got[:3], want):
+                assert x.shape == y.shape and _rays.same_bits(x, y).all(), seed
+            total += len(want[0])
+        assert total == 15 * n_seeds
+    # fewer photons than one path yields, and none at all
+    for n in (1, 2):
+        want = R.create_photon_map(sr, n, 7)
+        got = O.create_photon_map_u(so, R.draws(7, 500), n)
+        assert len(want[0]) == n and _rays.same_bits(got[0], want[0]).all()
+
+
 def test_render_deterministic_pixels_match_reference(both, tmp_path):
     """Pixels whose primary ray hits the light (or nothing) do not depend on the
     random stream: they pin the camera set-up and the pixel->buffer indexing."""
