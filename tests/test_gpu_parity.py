@@ -94,6 +94,9 @@ def test_closest_hit_random_scene_deep_tree(rt):
     sg = rt.HostScene.from_spec(spec)
     org, d = _rays.interior_rays(300000, seed=31)
     _assert_hits_equal(sg.intersect(org, d), so.intersect(org, d))
+    # ragged ends of the ray stream: fewer rays than a wave, one more than a wave, ...
+    for n in (1, 63, 64, 65, 257, 4097):
+        _assert_hits_equal(sg.intersect(org[:n], d[:n]), so.intersect(org[:n], d[:n]))
 
 
 def test_million_triangle_mesh(rt):

@@ -16,5 +16,5 @@ for how in (dict(mode=1, streams=1), dict(mode=1, streams=2), dict(mode=2)):
     dt = time.time() - t0
     same = "" if ref is None else (" same image: %s" % bool((rgb.view(np.uint32) == ref.view(np.uint32)).all()))
     ref = rgb if ref is None else ref
-    print(how, "%.1f ms  %.1f Msamples/s  %.1f Mrays/s  trace %.1f logic %.1f fused %.1f ms%s"
-          % (dt * 1e3, 784 * 784 * spp / dt / 1e6, st.rays / dt / 1e6, st.ms_trace, st.ms_logic, st.ms_fused, same), flush=True)
+    print(how, "%.1f ms  %.1f Msamples/s  %.1f Mrays/s  trace %.1f logic %.1f fused %.1f other %.1f ms%s"
+          % (dt * 1e3, 784 * 784 * spp / dt / 1e6, st.rays / dt / 1e6, st.ms_trace, st.ms_logic, st.ms_fused, st.ms_other, same), flush=True)
