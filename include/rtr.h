@@ -148,7 +148,8 @@ typedef struct rtr_render_params {
  * of Render::pathTracing, src/Render.cpp:84-133, :651-664) is run.  Same image
  * bit for bit in every mode.
  *   FUSED:     one persistent kernel, one path per lane, path state in registers;
- *              chosen for scenes small enough to be staged in LDS.
+ *              chosen for scenes small enough to be staged in LDS, and for trees of up
+ *              to 16 Ki nodes (which stay in cache).
  *   WAVEFRONT: a pool of paths in HBM, one path-logic and one traversal kernel per
  *              bounce, rays compacted into queues; chosen for everything else. */
 enum { RTR_MODE_AUTO = 0, RTR_MODE_WAVEFRONT = 1, RTR_MODE_FUSED = 2 };

@@ -119,10 +119,11 @@ def test_million_triangle_mesh(rt):
     sd_ = np.stack([rng.uniform(0.5, 1, 150), rng.uniform(-0.03, 0.03, 150), rng.uniform(-1, -0.5, 150)], 1).astype(f32)
     _assert_hits_equal(sg.intersect(so_, sd_), so.intersect(so_, sd_))
     img, stats = O.render(so, 32, 32, 4, seed=9, chunk_spp=2)
-    for how in (dict(mode=1), dict(mode=2)):
+    for how in (dict(), dict(mode=1), dict(mode=2)):
         rgb, st = sg.render(32, 32, 4, seed=9, chunk_spp=2, **how)
         _assert_images_equal(rgb, img)
         assert st.rays == stats[1] and st.vertices == stats[3]
+        assert st.mode == (how.get("mode") or rt.MODE_WAVEFRONT)  # a tree this large: wavefront by default
 
 
 def test_closest_hit_degenerate_triangles_nan_distance(rt):
@@ -409,9 +410,9 @@ def test_render_with_mesh_light(rt):
 
 
 def test_render_scene_too_large_for_lds(rt):
-    """A scene with a few hundred triangles takes the general traversal (per-lane tree
-    walk, geometry from HBM) and by default the wavefront loop; the fused kernel must
-    give the same image with it."""
+    """A scene with a few thousand triangles takes the general traversal (per-lane tree
+    walk, geometry from memory); its tree is small enough that the fused kernel is the
+    default.  Every loop variant must give the same image."""
     O = Oracle()
     spec = _random_scene_spec(5)
     so = O.build_scene(spec)
@@ -419,7 +420,7 @@ def test_render_scene_too_large_for_lds(rt):
     sg = rt.HostScene.from_spec(spec)
     want, stats = O.render(so, 40, 32, 6, seed=4, chunk_spp=3)
     rgb, st = sg.render(40, 32, 6, seed=4, chunk_spp=3)
-    assert st.mode == rt.MODE_WAVEFRONT
+    assert st.mode == rt.MODE_FUSED
     _assert_images_equal(rgb, want)
     assert st.rays == stats[1] and st.vertices == stats[3]
     for how in MODES:
