@@ -5,12 +5,13 @@
 //
 //   fused      k_render_fused: one persistent kernel, one path per lane, path state
 //              in registers, both rays of a vertex traced by the lane itself; for
-//              scenes small enough to be staged in LDS.
+//              scenes small enough to be staged in LDS (and small trees in general).
 //   wavefront  a loop of k_logic (consume last iteration's hits, Russian roulette
 //              result, path regeneration, light sampling, BSDF sampling, ray emission
-//              with 64-wide ballot compaction into the ray queue) and k_trace_queue
-//              (closest hit for every queued ray); path state lives in HBM as float4
-//              structure-of-arrays indexed by slot.
+//              with 64-wide ballot compaction into the ray queue) and a traversal kernel
+//              (closest hit for every queued ray: k_trace_queue for scenes in LDS,
+//              k_trace_queue_stream for trees read from memory); path state lives in HBM
+//              as float4 structure-of-arrays indexed by slot.
 //
 // A work unit is (pixel, chunk of consecutive samples).  A lane or slot sums its
 // unit's samples in order and writes ONE partial sum per unit, so the image needs

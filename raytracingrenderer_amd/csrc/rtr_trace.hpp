@@ -266,6 +266,28 @@ RTR_DEV bool fast_ray(V3 o, V3 dn) {
          fabsf(dn.x) <= 2.0f && fabsf(dn.y) <= 2.0f && fabsf(dn.z) <= 2.0f;
 }
 
+// slab_fast behind a cheap filter.  With y = RN(1/d), q' = RN(a*y) differs from the IEEE
+// quotient q = RN(a/d) by at most 3 ulp: |q' - q| <= 2^-22 |q'| (y and the product each
+// carry one rounding, q another; nothing under- or overflows under the preconditions
+// of slab_fast).  tnear and tfar are a max and a min of such values, so each is within
+// 2^-22 m of the reference's, m being the largest of the six |q'|.  If the computed gap
+// tfar' - tnear' exceeds 2^-20 m in magnitude, the reference's "tnear <= tfar" has the
+// sign of that gap; otherwise (a few tests in a million) the exact sequence decides.
+RTR_DEV bool slab_filtered(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
+  const f32x2 px = {lo.x, hi.x}, py = {lo.y, hi.y}, pz = {lo.z, hi.z};
+  const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f32x2 yx = {y.x, y.x}, yy = {y.y, y.y}, yz = {y.z, y.z};
+  const f32x2 qx = (px - ox) * yx, qy = (py - oy) * yy, qz = (pz - oz) * yz;
+  const float nx = fminf(qx.x, qx.y), ny = fminf(qy.x, qy.y), nz = fminf(qz.x, qz.y);
+  const float fx = fmaxf(qx.x, qx.y), fy = fmaxf(qy.x, qy.y), fz = fmaxf(qz.x, qz.y);
+  const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(nx), fabsf(ny)), fabsf(nz)),
+                        fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)));
+  const float gap = tf - tn;
+  if (fabsf(gap) > m * 9.5367431640625e-07f) return gap > 0.0f;  // 2^-20
+  return slab_fast(lo, hi, o, d, y);
+}
+
 // ---------------------------------------------------------------------------
 // Wave-cooperative closest hit.
 //
@@ -358,7 +380,7 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
       int skip = (int)wbits(lo);
       int leaf = (int)wbits(hi);
       bool pass;
-      if (fast) pass = slab_fast(lo, hi, o, dn, inv);
+      if (fast) pass = slab_filtered(lo, hi, o, dn, inv);
       else pass = slab(lo, hi, o, dn);
       if (pass && leaf < 0) {
         i = i + 1;
@@ -421,14 +443,7 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
 // pending primitive tests are flushed, finished lanes write their result and take
 // the next rays.
 //
-// Box tests go through a filter first.  With y = RN(1/d), q' = RN(a*y) differs
-// from the IEEE quotient q = RN(a/d) by at most 3 ulp: |q' - q| <= 2^-22 |q'|
-// (y and the product each carry one rounding, q another; nothing under- or
-// overflows under the preconditions of slab_fast).  tnear and tfar are a max and
-// a min of such values, so each is within 2^-22 m of the reference's, m being the
-// largest of the six |q'|.  If the computed gap tfar' - tnear' exceeds 2^-20 m in
-// magnitude, the reference's "tnear <= tfar" has the sign of that gap; otherwise
-// (a few tests in a million) the exact test decides.
+// Box tests go through slab_filtered.
 //
 // A refill is kept short, because the whole wave stands still for it: ring entries
 // carry the leaf, so a flush needs one round trip to memory, not two; both rings are
@@ -533,21 +548,6 @@ RTR_DEV void stream_round(const DeviceScene &sc, StreamWave &ws, unsigned head0,
   }
   ws.hit0[r] = make_float4(pos.x, pos.y, pos.z, t);
   ws.hit1[r] = make_float4(nrm.x, nrm.y, nrm.z, __int_as_float(leaf));
-}
-
-RTR_DEV bool slab_filtered(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
-  const f32x2 px = {lo.x, hi.x}, py = {lo.y, hi.y}, pz = {lo.z, hi.z};
-  const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-  const f32x2 yx = {y.x, y.x}, yy = {y.y, y.y}, yz = {y.z, y.z};
-  const f32x2 qx = (px - ox) * yx, qy = (py - oy) * yy, qz = (pz - oz) * yz;
-  const float nx = fminf(qx.x, qx.y), ny = fminf(qy.x, qy.y), nz = fminf(qz.x, qz.y);
-  const float fx = fmaxf(qx.x, qx.y), fy = fmaxf(qy.x, qy.y), fz = fmaxf(qz.x, qz.y);
-  const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
-  const float m = fmaxf(fmaxf(fmaxf(fabsf(nx), fabsf(ny)), fabsf(nz)),
-                        fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)));
-  const float gap = tf - tn;
-  if (fabsf(gap) > m * 9.5367431640625e-07f) return gap > 0.0f;  // 2^-20
-  return slab_fast(lo, hi, o, d, y);
 }
 
 #ifndef RTR_REFILL_AT
