@@ -67,7 +67,7 @@ typedef struct rtr_scene rtr_scene;
  * in light_tris[light_tri_begin[l] .. light_tri_begin[l+1]).
  */
 typedef struct rtr_scene_desc {
-  int32_t n_nodes;
+  int32_t n_nodes;  /* at most 2^26 */
   int32_t root;
   const float *node_bmin[3];
   const float *node_bmax[3];

@@ -231,6 +231,8 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     return fail(RTR_ERR_INVALID, "negative count");
   if (d->n_tris >= (1 << 30) || d->n_spheres >= (1 << 30))
     return fail(RTR_ERR_INVALID, "too many primitives");
+  // traversal packs a node index and a lane into 32 bits
+  if (d->n_nodes > (1 << 26)) return fail(RTR_ERR_INVALID, "too many nodes (at most 2^26)");
   if (d->n_nodes > 0) {
     if (int rc = check_xyz(d->node_bmin, "node_bmin")) return rc;
     if (int rc = check_xyz(d->node_bmax, "node_bmax")) return rc;

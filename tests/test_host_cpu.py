@@ -116,6 +116,10 @@ def test_scene_create_rejects_malformed_descriptions(rt):
     d.n_nodes = -1
     assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
     assert b"negative" in lib.rtr_last_error()
+    d = Desc()
+    d.n_nodes = (1 << 26) + 1
+    assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
+    assert b"too many nodes" in lib.rtr_last_error()
     # a two-node "tree" whose child points back at the root
     keep = []
 
