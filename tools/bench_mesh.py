@@ -25,3 +25,17 @@ def run():
 run()
 t0 = time.time(); run(); run(); dt = (time.time() - t0) / 2
 print("%d rays in %.1f ms: %.1f Mrays/s; hit fraction %.3f" % (nr, dt * 1e3, nr / dt / 1e6, float((prim >= 0).float().mean())))
+if "--json" in sys.argv:
+    # one line in the shape of bench.py's, for the large-scene traversal.  Algorithmic bytes:
+    # 32 B per node visited + 48 B per triangle / 16 B per sphere tested; the averages per ray
+    # (78.7 nodes, 7.5 primitives, nearly all triangles) were counted on the device with a
+    # -DRTR_STREAM_STATS build (tools/stream_stats.py) for exactly these rays.
+    import json
+    bytes_per_ray = 78.7 * 32 + 7.5 * 48
+    print(json.dumps({"metric": "closest-hit queries per second, 1 M-triangle scene", "value": nr / dt / 1e6,
+                      "unit": "Mrays/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "default scene + %dx%d height field (%d triangles), %d incoherent rays"
+                                 % (n, n, 2 * n * n, nr)},
+                      "roofline": {"kernel": "k_trace_api_stream", "bound": "hbm",
+                                   "achieved": bytes_per_ray * nr / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": bytes_per_ray * nr / dt / 1e9 / 8000.0, "bytes_per_ray": bytes_per_ray}}))
