@@ -188,7 +188,9 @@ int rtr_trace_closest(rtr_scene *scene, const float *org_xyz, const float *dir_x
                       int32_t *prim_id, float *t, float *pos_xyz, float *nrm_xyz);
 
 /* Same with DEVICE pointers on the scene's device; enqueues on `stream`
- * (a hipStream_t, NULL = default stream) and returns without synchronising. */
+ * (a hipStream_t, NULL = default stream) and returns without synchronising.
+ * For scenes too large for LDS every call takes the next of 64 per-scene ray
+ * counters: keep at most 64 calls of one scene in flight at a time. */
 int rtr_trace_closest_device(rtr_scene *scene, const float *d_org_xyz, const float *d_dir_xyz,
                              size_t n, int32_t *d_prim_id, float *d_t, float *d_pos_xyz,
                              float *d_nrm_xyz, void *stream);
