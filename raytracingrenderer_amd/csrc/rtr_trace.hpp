@@ -75,6 +75,18 @@ struct HitRec {
 
 constexpr int kMaxDepth = 64;
 
+// (double)x < L for a float x and a double literal L  <=>  x < ceil_to_float(L)
+constexpr float ceil_to_float(double L) {
+  float f = (float)L;
+  if ((double)f >= L) return f;
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u = f > 0 ? u + 1 : u - 1;
+  return __builtin_bit_cast(float, u);
+}
+constexpr float kTriEps = ceil_to_float(-1e-5);   // src/Trangle.cpp:17
+constexpr float kSphEps = ceil_to_float(1e-3);    // src/Sphere.cpp:29
+
+
 // Bound3::intersect, src/Bound3.cpp:3-22, with the direction already
 // normalised by the caller (the reference normalises the same vector on every
 // call, src/Bound3.cpp:5; the result is the same each time).
@@ -482,9 +494,8 @@ RTR_DEV bool hit_triangle_regs(float4 q0, float4 q1, float4 q2, V3 o, V3 dir, V3
   t = inv * dot(s2, e2);
   b1 = inv * dot(s1, s);
   b2 = inv * dot(s2, dn);
-  if ((double)t < -1e-5 || (double)b1 < -1e-5 || (double)b2 < -1e-5 ||
-      (double)(1 - b1 - b2) < -1e-5)
-    return false;
+  // float operands against the double literal -1e-5 (src/Trangle.cpp:17), as float compares
+  if (t < kTriEps || b1 < kTriEps || b2 < kTriEps || (1 - b1 - b2) < kTriEps) return false;
   return true;
 }
 RTR_DEV bool hit_sphere_regs(float4 q, V3 org, V3 d, float &t) {
@@ -500,7 +511,7 @@ RTR_DEV bool hit_sphere_regs(float4 q, V3 org, V3 d, float &t) {
   float sq = sqrtf(delta);
   float t1 = (-b + sq) / 2 / a;
   float t2 = (-b - sq) / 2 / a;
-  if ((double)t1 < 1e-3) return false;
+  if (t1 < kSphEps) return false;
   t = (t2 < 0) ? t1 : t2;
   return true;
 }
@@ -864,17 +875,6 @@ struct LeafRecord {
   int node, leaf;
 };
 typedef const LeafRecord __attribute__((address_space(4))) const_leaf;
-
-// (double)x < L for a float x and a double literal L  <=>  x < ceil_to_float(L)
-constexpr float ceil_to_float(double L) {
-  float f = (float)L;
-  if ((double)f >= L) return f;
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  u = f > 0 ? u + 1 : u - 1;
-  return __builtin_bit_cast(float, u);
-}
-constexpr float kTriEps = ceil_to_float(-1e-5);   // src/Trangle.cpp:17
-constexpr float kSphEps = ceil_to_float(1e-3);    // src/Sphere.cpp:29
 
 RTR_DEV bool quotient_operand_fast(float n) {
   // [2^-40, 2^40]; zero is left to the IEEE division: the corrections lose the sign
