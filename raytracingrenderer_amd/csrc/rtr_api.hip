@@ -113,7 +113,7 @@ struct rtr_scene {
 namespace {
 
 constexpr unsigned kTraceCounters = 64;
-constexpr int kFusedMaxNodes = 16384;  // RTR_MODE_AUTO: largest tree the fused kernel is chosen for
+constexpr int kFusedMaxNodes = 1 << 19;  // RTR_MODE_AUTO: largest tree the fused kernel is chosen for
 
 struct DeviceGuard {
   int prev = 0;
@@ -885,8 +885,9 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   // mode: one persistent kernel with path state in registers (scenes whose traversal
   // needs no per-wave queues), or the wavefront loop over a pool of paths in HBM
   if (prm->mode < 0 || prm->mode > 2) return fail(RTR_ERR_INVALID, "mode must be 0, 1 or 2");
-  // (measured on height-field meshes: at 6 K nodes the fused kernel with the per-lane walk
-  // renders 15 % faster than the wavefront loop, at 40 K nodes 10 % slower, at 2 M half as fast)
+  // (measured on height-field meshes at 64 spp, fused kernel against wavefront loop:
+  // 6 K nodes 1062 : 708 Msamples/s, 40 K nodes 897 : 654, 360 K nodes 558 : 542,
+  // 2 M nodes 372 : 396)
   const bool fused = prm->mode == RTR_MODE_FUSED ||
                      (prm->mode == RTR_MODE_AUTO && (s->lds_geometry || s->ds.n_nodes <= kFusedMaxNodes));
   if (fused) pool = kLogicBlock * kGroup;  // the wavefront buffers are not used

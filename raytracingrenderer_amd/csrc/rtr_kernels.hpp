@@ -124,7 +124,8 @@ RTR_DEV HitRec trace_any(const DeviceScene &sc, const LdsScene &lds, bool valid,
   if constexpr (kLds) {
     return trace_all(sc, lds, valid, o, d, dn, ws.merge);
   } else {
-    return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, valid, o, d, dn, ws);
+    return trace_wave(global_geom(sc), sc.n_nodes, sc.fast_planes != 0, sc.nested_boxes != 0, valid, o, d, dn,
+                      ws);
   }
 }
 

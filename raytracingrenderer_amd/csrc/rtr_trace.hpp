@@ -369,22 +369,71 @@ RTR_DEV void test_round(const Geom &g, WaveShared &ws, unsigned head, unsigned c
 
 // Scene::intersect for the 64 rays of a wave.  Must be called by all 64 lanes
 // (valid = false for lanes without a ray).
+//
+// The number of nodes a ray visits varies by orders of magnitude (nothing is culled by
+// distance), so with can_split lanes whose ray is finished -- or that never had one --
+// take the upper half of the node range of lanes that still walk.  Any node may start a
+// walk when boxes are nested (can_split says they are) and the ray's arithmetic is
+// finite: a box that passes implies that all its ancestors pass (their near/far
+// quotients enclose the child's, rounding being monotone), so nodes below a missed box
+// miss as well and no test is made that the reference would not make; results merge
+// through the order-independent key minimum of the ray's slot.
+#ifndef RTR_WAVE_SPLIT_AT
+#define RTR_WAVE_SPLIT_AT 32
+#endif
+#ifndef RTR_WAVE_SPLIT_MIN
+#define RTR_WAVE_SPLIT_MIN 8
+#endif
 template <class Geom>
-RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool valid, V3 o, V3 dir,
-                          V3 dn, WaveShared &ws) {
+RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool can_split, bool valid,
+                          V3 o, V3 dir, V3 dn, WaveShared &ws) {
   const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
   ws.w.ray0[lane] = make_float4(o.x, o.y, o.z, dir.x);
   ws.w.ray1[lane] = make_float4(dir.y, dir.z, dn.x, dn.y);
-  ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);
+  ws.w.ray2[lane] = make_float4(dn.z, 0.0f, 0.0f, 0.0f);  // .yzw: hand-over of split ranges
   ws.w.key[lane] = ~0ull;
   if (lane == 0) ws.nan_mask = 0;
-  const bool fast = fast_planes && fast_ray(o, dn);
-  const V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+  // the walk's ray: the lane's own (slot r == lane) or, after a split, another slot's
+  bool fast = fast_planes && fast_ray(o, dn);
+  V3 wo = o, wdn = dn;
+  V3 inv = mk(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+  unsigned r = lane;
   unsigned head[2] = {0, 0}, tail[2] = {0, 0};  // wave-uniform ring cursors
-  int i = 0;
+  int i = 0, end = valid ? n_nodes : 0;
   for (;;) {
-    const bool alive = valid && i < n_nodes;
-    if (__ballot(alive) == 0) break;
+    const bool alive = i < end;
+    const unsigned long long am = __ballot(alive);
+    if (am == 0) break;
+    if (can_split && (unsigned)__popcll(am) <= RTR_WAVE_SPLIT_AT) {
+      const bool victim = alive && fast && end - i >= RTR_WAVE_SPLIT_MIN;
+      const unsigned long long vm = __ballot(victim), tm = ~am;
+      const unsigned nv = (unsigned)__popcll(vm), nt = (unsigned)__popcll(tm);
+      const unsigned pairs = nv < nt ? nv : nt;
+      if (pairs) {
+        const unsigned vr = (unsigned)__popcll(vm & below), tr = (unsigned)__popcll(tm & below);
+        if (victim && vr < pairs) {
+          const int mid = i + (end - i) / 2;
+          float4 *x = &ws.w.ray2[vr];
+          x->y = __int_as_float(mid);
+          x->z = __int_as_float(end);
+          x->w = __int_as_float((int)r);
+          end = mid;
+        }
+        if (!alive && tr < pairs) {  // LDS operations of a wave execute in order
+          const float4 x = ws.w.ray2[tr];
+          i = __float_as_int(x.y);
+          end = __float_as_int(x.z);
+          r = (unsigned)__float_as_int(x.w);
+          const float4 a0 = ws.w.ray0[r], a1 = ws.w.ray1[r];
+          wo = mk(a0.x, a0.y, a0.z);
+          wdn = mk(a1.z, a1.w, ws.w.ray2[r].x);
+          inv = mk(1.0f / wdn.x, 1.0f / wdn.y, 1.0f / wdn.z);
+          fast = true;
+        }
+        continue;
+      }
+    }
     bool cand = false;
     int kind = 0, node = i;
     if (alive) {
@@ -392,8 +441,8 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
       int skip = (int)wbits(lo);
       int leaf = (int)wbits(hi);
       bool pass;
-      if (fast) pass = slab_filtered(lo, hi, o, dn, inv);
-      else pass = slab(lo, hi, o, dn);
+      if (fast) pass = slab_filtered(lo, hi, wo, wdn, inv);
+      else pass = slab(lo, hi, wo, wdn);
       if (pass && leaf < 0) {
         i = i + 1;
       } else {
@@ -405,7 +454,7 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
     unsigned long long m0 = __ballot(cand && kind == 0), m1 = __ballot(cand && kind != 0);
     if (m0) {
       if (cand && kind == 0)
-        ws.w.ring[0][(tail[0] + __popcll(m0 & ((1ull << lane) - 1ull))) & 127u] = lane | ((uint32_t)node << 6);
+        ws.w.ring[0][(tail[0] + __popcll(m0 & below)) & 127u] = r | ((uint32_t)node << 6);
       tail[0] += (unsigned)__popcll(m0);
       if (tail[0] - head[0] >= 64u) {
         test_round<0>(g, ws, head[0], 64u);
@@ -414,7 +463,7 @@ RTR_DEV HitRec trace_wave(const Geom &g, int n_nodes, bool fast_planes, bool val
     }
     if (m1) {
       if (cand && kind != 0)
-        ws.w.ring[1][(tail[1] + __popcll(m1 & ((1ull << lane) - 1ull))) & 127u] = lane | ((uint32_t)node << 6);
+        ws.w.ring[1][(tail[1] + __popcll(m1 & below)) & 127u] = r | ((uint32_t)node << 6);
       tail[1] += (unsigned)__popcll(m1);
       if (tail[1] - head[1] >= 64u) {
         test_round<1>(g, ws, head[1], 64u);
