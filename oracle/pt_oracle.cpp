@@ -1021,6 +1021,47 @@ void top_leaves(const orc_scene *s, int node, std::vector<int32_t> &out) {
 }
 } // namespace
 
+namespace {
+/* finds flattened node `want` by the walk of flat_top / flat_mesh and overwrites its box */
+bool set_box_mesh(Object &m, int node, int &next, int want, const Box &b) {
+  Node &nd = m.tree.nodes[node];
+  if (next++ == want) {
+    nd.box = b;
+    return true;
+  }
+  if (nd.left < 0 && nd.right < 0) return false;
+  return set_box_mesh(m, nd.left, next, want, b) || set_box_mesh(m, nd.right, next, want, b);
+}
+bool set_box_top(orc_scene *s, int node, int &next, int want, const Box &b) {
+  Node &nd = s->top.nodes[node];
+  if (nd.left < 0 && nd.right < 0) {
+    Object &ob = s->objs[nd.item];
+    if (ob.kind == 1) {
+      /* the top-level leaf and the mesh's root share one flattened node: both boxes */
+      if (next == want) nd.box = b;
+      return set_box_mesh(ob, ob.tree.root, next, want, b);
+    }
+    if (next++ == want) {
+      nd.box = b;
+      return true;
+    }
+    return false;
+  }
+  if (next++ == want) {
+    nd.box = b;
+    return true;
+  }
+  return set_box_top(s, nd.left, next, want, b) || set_box_top(s, nd.right, next, want, b);
+}
+} // namespace
+
+int orc_set_node_box(orc_scene *s, int flat_index, const float lo[3], const float hi[3]) {
+  int next = 0;
+  if (s->top.root < 0) return -1;
+  Box b(mk(lo[0], lo[1], lo[2]), mk(hi[0], hi[1], hi[2]));
+  return set_box_top(s, s->top.root, next, flat_index, b) ? 0 : -1;
+}
+
 int orc_flatten(const orc_scene *s, float *bmin3, float *bmax3, int32_t *child2, int32_t *prim) {
   Flat f;
   if (s->top.root >= 0) flat_top(s, s->top.root, f);

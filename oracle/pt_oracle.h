@@ -73,6 +73,10 @@ int orc_flatten(const orc_scene *s, float *bmin3, float *bmax3,
                 int32_t *node_child2, int32_t *node_prim);
 /* leaf prim ids in left-to-right DFS order of the top-level tree (object ids)*/
 int orc_top_leaf_order(const orc_scene *s, int32_t *object_ids);
+/* Overwrites the box of node `flat_index` (numbering of orc_flatten), so that trees whose
+ * boxes are NOT nested can be checked: the reference tests whatever box a node carries
+ * (src/BVH.cpp:66-80), a child is only reached through its ancestors' boxes. */
+int orc_set_node_box(orc_scene *s, int flat_index, const float lo[3], const float hi[3]);
 float orc_object_area(const orc_scene *s, int object);
 
 /* ---- closest hit: Scene::intersect, include/Scene.h:46 ---- */

@@ -103,6 +103,22 @@ int flat_node(RefScene *r, BVHNode *n, bool top, Flat &f) {
   return id;
 }
 
+/* the walk of flat_node, looking for flattened node `want`: overwrites the reference's own
+ * BVHNode::bound (the top-level leaf of a mesh and the mesh's root are one flattened node) */
+bool set_bound(RefScene *r, BVHNode *n, bool top, int &next, int want, const Bound3 &b) {
+  if (top && n->object != nullptr && r->kinds[r->object_of[n->object]] == 1) {
+    TrangleMesh *m = (TrangleMesh *)n->object;
+    if (next == want) n->bound = b;
+    return set_bound(r, m->bvh->root, false, next, want, b);
+  }
+  if (next++ == want) {
+    n->bound = b;
+    return true;
+  }
+  if (n->object != nullptr) return false;
+  return set_bound(r, n->left, top, next, want, b) || set_bound(r, n->right, top, next, want, b);
+}
+
 void top_leaves(RefScene *r, BVHNode *n, std::vector<int32_t> &out) {
   if (n->object != nullptr) {
     out.push_back(r->object_of[n->object]);
@@ -285,6 +301,14 @@ void ref_path_trace(void *h, const float org[3], const float dir[3], uint32_t se
   Ray ray(v3(org), v3(dir));
   Vector3f c = r->render.pathTracing(*r->scene, ray);
   rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+
+/* Overwrites the box of flattened node `flat_index` in the reference's tree. */
+int ref_set_node_box(void *h, int flat_index, const float lo[3], const float hi[3]) {
+  RefScene *r = (RefScene *)h;
+  int next = 0;
+  Bound3 b(v3(lo), v3(hi));
+  return set_bound(r, r->scene->bvh->root, true, next, flat_index, b) ? 0 : -1;
 }
 
 /* Render::createPhotonMap after seeding.  photon_num must be below 16: the reference then

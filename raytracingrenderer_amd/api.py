@@ -126,6 +126,7 @@ def host_lib():
         L.rtrh_material_id.argtypes = [C.c_void_p, C.c_int]
         L.rtrh_intersect.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, _ip, _fp, _fp, _fp]
         L.rtrh_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_int64, C.POINTER(C.c_uint8)]
+        L.rtrh_set_node_box.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.rtrh_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp, _fp]
         L.rtrh_create_photon_map.restype = C.c_int64
         L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
@@ -246,6 +247,14 @@ class HostScene:
         prim = np.zeros(n, np.int32)
         self.L.rtrh_flatten(self.h, _f(lo), _f(hi), _i(child), _i(prim))
         return lo, hi, child, prim
+
+    def set_node_box(self, flat_index, lo, hi):
+        """Scene::setNodeBound: overwrite one node's box (numbering of flatten())."""
+        lo = np.ascontiguousarray(lo, f32)
+        hi = np.ascontiguousarray(hi, f32)
+        if self.L.rtrh_set_node_box(self.h, int(flat_index), _f(lo), _f(hi)) != 0:
+            raise RtrError("no node %d" % flat_index)
+        self._dev = None
 
     def num_prims(self):
         return self.L.rtrh_num_prims(self.h)

@@ -358,6 +358,34 @@ struct Flattener {
 
 }  // namespace
 
+namespace {
+// the walk of Flattener::add_node, looking for flattened node `want`
+bool set_bound(BVHNode *n, int &next, int want, const Bound3 &b) {
+  if (n->object && n->object->kind() == Object::MESH) {
+    BVHNode *inner = const_cast<BVHNode *>(static_cast<const TrangleMesh *>(n->object)->getBVH()->getRoot());
+    if (inner) {
+      if (next == want) n->bound = b;  // the top-level leaf and the mesh's root are one flattened node
+      return set_bound(inner, next, want, b);
+    }
+  }
+  if (next++ == want) {
+    n->bound = b;
+    return true;
+  }
+  if (n->object) return false;
+  return set_bound(n->left, next, want, b) || set_bound(n->right, next, want, b);
+}
+}  // namespace
+
+bool Scene::setNodeBound(int flatIndex, const Bound3 &b) {
+  BVHNode *root = const_cast<BVHNode *>(bvh->getRoot());
+  if (!root || flatIndex < 0) return false;
+  int next = 0;
+  if (!set_bound(root, next, flatIndex, b)) return false;
+  flatValid = false;
+  return true;
+}
+
 rtr_scene_desc FlatScene::desc() const {
   rtr_scene_desc d;
   memset(&d, 0, sizeof(d));
@@ -735,6 +763,13 @@ int rtrh_intersect(void *hs, const float *org, const float *dir, int64_t n, int3
                    float *pos, float *nrm) {
   HostScene *h = (HostScene *)hs;
   return guarded([&] { h->scene->intersectBatch(org, dir, (size_t)n, prim, t, pos, nrm); });
+}
+
+int rtrh_set_node_box(void *hs, int flat_index, const float *lo, const float *hi) {
+  HostScene *h = (HostScene *)hs;
+  bool found = false;
+  int rc = guarded([&] { found = h->scene->setNodeBound(flat_index, Bound3(v3(lo), v3(hi))); });
+  return rc ? rc : (found ? 0 : -1);
 }
 
 int rtrh_check_connectable(void *hs, const float *a, const float *b, int64_t n, uint8_t *connected) {

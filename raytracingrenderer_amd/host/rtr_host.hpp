@@ -239,6 +239,9 @@ class Scene {
   void checkConnectableBatch(const float *a_xyz, const float *b_xyz, size_t n, uint8_t *connected);
 
   void setDevice(int index);
+  // Overwrites the box of node flatIndex (numbering of flatten()): for trees built elsewhere,
+  // whose boxes need not contain their children's.  Returns false if there is no such node.
+  bool setNodeBound(int flatIndex, const Bound3 &b);
   const FlatScene &flatten();  // (re)built after rebuildBVH
   rtr_scene *deviceScene();    // uploaded on first use; throws if no device
   const std::vector<Object *> &getLights() const { return lights; }

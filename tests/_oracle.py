@@ -215,6 +215,7 @@ class Oracle(_Backend):
         L.orc_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
         L.orc_tonemap.argtypes = [C.c_float]
         L.orc_tonemap.restype = C.c_ubyte
+        L.orc_set_node_box.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.orc_photon_path.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp, _fp]
         L.orc_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, _fp, _fp, _fp, _up]
         L.orc_create_photon_map.restype = C.c_int64
@@ -223,6 +224,11 @@ class Oracle(_Backend):
     def default_scene(self):
         ids = {m[0]: i for i, m in enumerate(default_scene_spec()["materials"])}
         return Scene(self, self.lib.orc_default_scene(), ids)
+
+    def set_node_box(self, scene, flat_index, lo, hi):
+        lo = np.ascontiguousarray(lo, f32)
+        hi = np.ascontiguousarray(hi, f32)
+        assert self.lib.orc_set_node_box(scene.h, int(flat_index), _f(lo), _f(hi)) == 0
 
     def set_math(self, scene, portable):
         self.lib.orc_set_math(scene.h, 1 if portable else 0)
@@ -329,6 +335,7 @@ class Ref(_Backend):
         L.ref_sample_light.argtypes = [C.c_void_p, C.c_uint32, _fp, _fp, _fp, _ip]
         L.ref_path_trace.argtypes = [C.c_void_p, _fp, _fp, C.c_uint32, _fp]
         L.ref_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, _fp]
+        L.ref_set_node_box.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.ref_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint, _fp, _fp, _fp]
 
     def default_scene(self):
@@ -361,6 +368,11 @@ class Ref(_Backend):
         rgb = np.zeros(3, f32)
         self.lib.ref_path_trace(scene.h, _f(org), _f(d), seed, _f(rgb))
         return rgb
+
+    def set_node_box(self, scene, flat_index, lo, hi):
+        lo = np.ascontiguousarray(lo, f32)
+        hi = np.ascontiguousarray(hi, f32)
+        assert self.lib.ref_set_node_box(scene.h, int(flat_index), _f(lo), _f(hi)) == 0
 
     def create_photon_map(self, scene, n, seed):
         """Render::createPhotonMap (n < 16: one thread, reproducible): (pos, wi, power)."""

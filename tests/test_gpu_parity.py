@@ -203,6 +203,50 @@ def test_photon_map_large_scene_and_no_lights(rt):
     assert len(got[0]) == 0 and got[3] == 0
 
 
+def _unnest(O, so, sg, seed, share):
+    """Shrinks and shifts a share of the nodes' boxes (the same in the checker's and the
+    library's scene), so that boxes no longer contain their children's."""
+    rng = np.random.default_rng(seed)
+    lo, hi, child, prim = sg.flatten()
+    n = len(prim)
+    for k in rng.choice(n, max(1, int(share * n)), replace=False):
+        ext = hi[k] - lo[k]
+        nlo = (lo[k] + rng.uniform(-0.2, 0.6, 3) * ext).astype(f32)
+        nhi = np.maximum(nlo, (hi[k] - rng.uniform(-0.2, 0.6, 3) * ext).astype(f32))
+        sg.set_node_box(k, nlo, nhi)
+        O.set_node_box(so, k, nlo, nhi)
+
+
+def test_trees_whose_boxes_are_not_nested(rt):
+    """The reference tests whatever box a node carries, and reaches a child only through
+    its ancestors' boxes.  With boxes that do not contain their children's, the short cuts
+    that rely on nesting (leaf box alone decides; a walk may start at any node) must be off:
+    closest hits, visibility and images still equal the checker's, on a scene staged in LDS
+    and on one walked in memory."""
+    O = Oracle()
+    for spec, share in ((default_scene_spec(), 0.3), (_random_scene_spec(3), 0.1)):
+        so = O.build_scene(spec)
+        O.set_math(so, portable=True)
+        sg = rt.HostScene.from_spec(spec)
+        _unnest(O, so, sg, 17, share)
+        org, d = _rays.interior_rays(150000, seed=41)
+        want = so.intersect(org, d)
+        _assert_hits_equal(sg.intersect(org, d), want)
+        nested = rt.HostScene.from_spec(spec).intersect(org, d)
+        assert (nested[0] != want[0]).mean() > 0.01    # the boxes do cut hits away
+        a, b = _rays.connection_pairs(so, 20000, 5)
+        assert np.array_equal(sg.check_connectable(a, b), so.check_connectable(a, b))
+        img, stats = O.render(so, 40, 30, 4, seed=2, chunk_spp=2)
+        for how in MODES:
+            rgb, st = sg.render(40, 30, 4, seed=2, chunk_spp=2, **how)
+            _assert_images_equal(rgb, img)
+            assert st.rays == stats[1] and st.vertices == stats[3]
+        want = O.create_photon_map(so, 3000, 6)
+        got = sg.create_photon_map(3000, 6)
+        for x, y in zip(got[:3], want[:3]):
+            assert x.shape == y.shape and _rays.same_bits(x, y).all()
+
+
 def test_check_connectable(rt, scenes):
     """Scene::checkConnectable on the default scene (all-leaves traversal) and on a scene
     with thousands of primitives (tree walk): same booleans as the checker."""

@@ -84,6 +84,24 @@ def test_host_flatten_matches_checker_grid_mesh_with_tied_keys(rt):
         assert np.array_equal(_rays.bits(a), _rays.bits(b))
 
 
+def test_node_box_override_matches_checker(rt):
+    """Scene::setNodeBound and the checker's orc_set_node_box address the same nodes."""
+    O = Oracle()
+    so = O.default_scene()
+    sh = rt.default_scene()
+    lo, hi, child, prim = sh.flatten()
+    for k in (0, 3, 11, len(prim) - 1):
+        nlo, nhi = lo[k] + f32(1.5), hi[k] - f32(0.25)
+        sh.set_node_box(k, nlo, nhi)
+        O.set_node_box(so, k, nlo, nhi)
+    fh, fo = sh.flatten(), so.flatten()
+    for a, b in zip(fh, fo):
+        assert np.array_equal(_rays.bits(a), _rays.bits(b))
+    assert not np.array_equal(fh[0], lo)
+    with pytest.raises(rt.RtrError):
+        sh.set_node_box(len(prim), lo[0], hi[0])
+
+
 def _desc_for(rt, spec):
     """Build an rtr_scene_desc by hand (ctypes) from the host library's arrays."""
     class Desc(C.Structure):

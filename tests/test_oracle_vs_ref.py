@@ -112,6 +112,39 @@ def test_grid_mesh_with_tied_sort_keys(both):
         assert np.array_equal(_rays.bits(a), _rays.bits(b))
 
 
+def test_boxes_that_are_not_nested(both):
+    """Node boxes overwritten so that they no longer contain their children's (the same in
+    the reference's own BVHNode::bound): closest hits and whole paths still agree."""
+    O, R, _, _ = both
+    rng = np.random.default_rng(12)
+    spec = default_scene_spec()
+    pts = rng.uniform(0, 512, (300, 3)).astype(f32) * np.array([1, 1, -1], f32)
+    spec["objects"] = spec["objects"] + [("mesh", "white", pts, rng.integers(0, 300, 600).astype(np.uint32))]
+    so, sr = O.build_scene(spec), R.build_scene(spec)
+    lo, hi, child, prim = so.flatten()
+    for k in rng.choice(len(prim), len(prim) // 4, replace=False):
+        ext = hi[k] - lo[k]
+        nlo = (lo[k] + rng.uniform(-0.2, 0.6, 3) * ext).astype(f32)
+        nhi = np.maximum(nlo, (hi[k] - rng.uniform(-0.2, 0.6, 3) * ext).astype(f32))
+        O.set_node_box(so, k, nlo, nhi)
+        R.set_node_box(sr, k, nlo, nhi)
+    for a, b in zip(so.flatten(), sr.flatten()):
+        assert np.array_equal(_rays.bits(a), _rays.bits(b))
+    org, d = _rays.interior_rays(40000, seed=8)
+    po, to, poso, no = so.intersect(org, d)
+    pr, tr, posr, nr = sr.intersect(org, d)
+    assert np.array_equal(po, pr)
+    hit = po >= 0
+    assert _rays.same_bits(to, tr)[hit].all() and _rays.same_bits(poso, posr)[hit].all()
+    nested = O.build_scene(spec).intersect(org, d)
+    assert (nested[0] != po).mean() > 0.01
+    for k in range(300):
+        u = R.draws(1000 + k, 600)
+        want = R.path_trace(sr, org[k], d[k], 1000 + k)
+        got, used = O.path_trace_u(so, org[k], d[k], u)
+        assert used < 600 and _rays.same_bits(got, want).all(), k
+
+
 def test_check_connectable(both):
     """Scene::checkConnectable, include/Scene.h:49-56: same booleans on surface-point pairs
     (about 40 % connected), degenerate pairs included; also on a random scene."""
