@@ -203,6 +203,38 @@ def test_photon_map_large_scene_and_no_lights(rt):
     assert len(got[0]) == 0 and got[3] == 0
 
 
+def _scaled(spec, k):
+    out = dict(spec)
+    cam = dict(spec["camera"]) if isinstance(spec["camera"], dict) else spec["camera"]
+    objs = []
+    for ob in spec["objects"]:
+        if ob[0] == "sphere":
+            objs.append(("sphere", ob[1], tuple(float(c) * k for c in ob[2]), float(ob[3]) * k))
+        else:
+            objs.append(("mesh", ob[1], (np.asarray(ob[2], f32) * f32(k)).astype(f32), ob[3]))
+    out["objects"] = objs
+    out["camera"] = cam
+    return out
+
+
+def test_scenes_outside_the_division_free_ranges(rt):
+    """The division-free box test and sphere roots are only used while box planes, origins
+    and quotients stay inside fixed ranges.  Scenes scaled by 2^23 (coordinates up to 2^32)
+    and by 2^-27 (down to 2^-21) leave them, partly or wholly; every ray then takes the
+    IEEE divisions.  Same hits as the checker, bit for bit."""
+    O = Oracle()
+    for base in (default_scene_spec(), _random_scene_spec(4, n_tri=800, n_sph=20)):
+        for k in (2.0 ** 23, 2.0 ** -27, 2.0 ** 19, 2.0 ** -12):
+            spec = _scaled(base, k)
+            so = O.build_scene(spec)
+            sg = rt.HostScene.from_spec(spec)
+            org, d = _rays.interior_rays(40000, seed=9)
+            org = (org * f32(k)).astype(f32)
+            want = so.intersect(org, d)
+            _assert_hits_equal(sg.intersect(org, d), want)
+            assert (want[0] >= 0).mean() > 0.02   # the reference itself loses most hits at 2^23
+
+
 def _unnest(O, so, sg, seed, share):
     """Shrinks and shifts a share of the nodes' boxes (the same in the checker's and the
     library's scene), so that boxes no longer contain their children's."""
