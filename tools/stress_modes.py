@@ -26,7 +26,9 @@ def lights():
     return spec
 
 cases = [("default", default_scene_spec(), dict()), ("variant d16 rr.95", variant(), dict(max_depth=16, rr_prob=0.95)),
-         ("three lights", lights(), dict()), ("heightfield 64", _rays.heightfield_spec(64), dict())]
+         ("three lights", lights(), dict()), ("heightfield 64", _rays.heightfield_spec(64), dict()),
+         ("heightfield 300", _rays.heightfield_spec(300), dict()),
+         ("heightfield 300 d16 rr.95", _rays.heightfield_spec(300), dict(max_depth=16, rr_prob=0.95))]
 ok = True
 for name, spec, kw in cases:
     sg = rt.HostScene.from_spec(spec)
