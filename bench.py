@@ -48,6 +48,14 @@ def cpu_baseline(W, H):
         cores = min(cores, aff)
     except Exception:
         pass
+    model = "unknown cpu"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     if have_ref():
         R = Ref()
         sr = R.default_scene()
@@ -66,8 +74,8 @@ def cpu_baseline(W, H):
         return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": 16,
                 "kind": "reference",
                 "sample": "%dx%d at %d spp, Render::renderPathTracing with its 16 std::threads "
-                          "(includes its PPM write), %.1f s; host exposes %d cpus"
-                          % (W, H, spp, dt, cores)}
+                          "(includes its PPM write), %.1f s; host exposes %d cpus (%s)"
+                          % (W, H, spp, dt, cores, model)}
     O = Oracle()
     so = O.default_scene()
     threads = min(cores, 16)
@@ -76,7 +84,7 @@ def cpu_baseline(W, H):
     O.render(so, W, H, spp, seed=0, threads=threads, recursive=True)
     dt = time.perf_counter() - t0
     return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads,
-            "kind": "port", "sample": "%dx%d at %d spp, %.1f s" % (W, H, spp, dt)}
+            "kind": "port", "sample": "%dx%d at %d spp, %.1f s (%s)" % (W, H, spp, dt, model)}
 
 
 def main():
