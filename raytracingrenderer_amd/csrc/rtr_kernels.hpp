@@ -109,6 +109,9 @@ k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4
 }
 
 // ---- traversal over explicit ray arrays (the rtr_trace_closest entry point) ----
+// k_trace_api, k_check_connectable and k_trace_queue are launched for scenes staged in LDS
+// (kLds = true); trees read from memory take the *_stream kernels further down, which
+// keep lanes busy across rays.  k_trace_primary and k_render_fused run in both flavours.
 // Closest hit for the 64 rays of a wave, from staged (LDS) or global geometry;
 // kLds is chosen by the host from the scene's size.  Every lane of the wave must
 // call this (valid = false where there is no ray).
