@@ -149,7 +149,7 @@ typedef struct rtr_render_params {
  * bit for bit in every mode.
  *   FUSED:     one persistent kernel, one path per lane, path state in registers;
  *              chosen for scenes small enough to be staged in LDS, and for trees of up
- *              to 2^17 nodes.
+ *              to 2^19 nodes.
  *   WAVEFRONT: a pool of paths in HBM, one path-logic and one traversal kernel per
  *              bounce, rays compacted into queues; chosen for everything else. */
 enum { RTR_MODE_AUTO = 0, RTR_MODE_WAVEFRONT = 1, RTR_MODE_FUSED = 2 };

@@ -113,7 +113,7 @@ struct rtr_scene {
 namespace {
 
 constexpr unsigned kTraceCounters = 64;
-constexpr int kFusedMaxNodes = 1 << 17;  // RTR_MODE_AUTO: largest tree the fused kernel is chosen for
+constexpr int kFusedMaxNodes = 1 << 19;  // RTR_MODE_AUTO: largest tree the fused kernel is chosen for
 
 struct DeviceGuard {
   int prev = 0;
@@ -885,10 +885,9 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   // mode: one persistent kernel with path state in registers (scenes whose traversal
   // needs no per-wave queues), or the wavefront loop over a pool of paths in HBM
   if (prm->mode < 0 || prm->mode > 2) return fail(RTR_ERR_INVALID, "mode must be 0, 1 or 2");
-  // (measured on height-field meshes at 64 spp, fused kernel against wavefront loop:
-  // 6 K nodes 1062 : 708 Msamples/s, 40 K nodes 897 : 654, 360 K nodes 558 : 542,
-  // 2 M nodes 372 : 396; at 256 spp the wavefront loop gains: 90 K nodes 783 : 769,
-  // 160 K nodes 663 : 732, 360 K nodes 570 : 671)
+  // (measured on height-field meshes, fused kernel against wavefront loop, Msamples/s:
+  // 6 K nodes 1255 : 708 and 360 K nodes 674 : 545 at 64 spp; 160 K nodes 811 : 735,
+  // 360 K nodes 691 : 672 and 2 M nodes 401 : 460 at 256 spp)
   const bool fused = prm->mode == RTR_MODE_FUSED ||
                      (prm->mode == RTR_MODE_AUTO && (s->lds_geometry || s->ds.n_nodes <= kFusedMaxNodes));
   if (fused) pool = kLogicBlock * kGroup;  // the wavefront buffers are not used
