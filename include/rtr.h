@@ -128,14 +128,20 @@ typedef struct rtr_camera {
  *
  * Sample values do not depend on the partition, the pool size or the device:
  * every uniform number is Philox4x32-10 of (pixel, sample, bounce, block) under
- * key (seed, 0), pixel = i*height + j.
+ * key (seed, 0), pixel = i*height + j.  For a given chunk_spp the image is the
+ * same bit for bit however it is partitioned, in every mode and on any number of
+ * devices.
  */
 typedef struct rtr_render_params {
   int32_t width, height, spp;
   uint32_t seed;
   int32_t max_depth;  /* <=0: unbounded */
   float rr_prob;      /* <=0: 0.6f */
-  int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: ceil(spp / 128) */
+  int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: chosen by the library
+                         (128 partial sums per pixel, fewer for images beyond about 1000 x
+                         1000 pixels).  It fixes the order in which a pixel's samples are
+                         added up and therefore the low bits of the image: compare images
+                         rendered with the same chunk_spp (rtr_stats.chunk_spp reports it) */
   int32_t pool_size;  /* wavefront mode: concurrent paths; <=0: auto (2^21, or 2^22 for scenes too large for LDS) */
   int32_t part_index, part_count, tile_cols;
   int32_t profile;    /* 1: bracket every kernel with events on the launch stream */
@@ -166,6 +172,9 @@ typedef struct rtr_stats {
   uint64_t trace_launches; /* number of traversal-kernel launches */
   double ms_fused;         /* only with profile=1: the fused sampling kernel */
   uint64_t fused_launches; /* 1 in RTR_MODE_FUSED (0 when no pixel needed sampling) */
+  double ms_gather;        /* rtr_render_pt_multi: last partition rendered -> whole image in place */
+  int32_t n_devices;       /* partitions rendered concurrently (1 for the single-device calls) */
+  int32_t reserved;
 } rtr_stats;
 
 const char *rtr_last_error(void);
@@ -190,7 +199,8 @@ int rtr_trace_closest(rtr_scene *scene, const float *org_xyz, const float *dir_x
 /* Same with DEVICE pointers on the scene's device; enqueues on `stream`
  * (a hipStream_t, NULL = default stream) and returns without synchronising.
  * For scenes too large for LDS every call takes the next of 64 per-scene ray
- * counters: keep at most 64 calls of one scene in flight at a time. */
+ * counters; with 64 calls of one scene still in flight the next call waits for
+ * the oldest to finish before it enqueues. */
 int rtr_trace_closest_device(rtr_scene *scene, const float *d_org_xyz, const float *d_dir_xyz,
                              size_t n, int32_t *d_prim_id, float *d_t, float *d_pos_xyz,
                              float *d_nrm_xyz, void *stream);
@@ -271,6 +281,29 @@ int rtr_render_pt(rtr_scene *scene, const rtr_camera *camera, const rtr_render_p
  * scene's stream before returning. */
 int rtr_render_pt_device(rtr_scene *scene, const rtr_camera *camera,
                          const rtr_render_params *params, float *d_rgb_out, rtr_stats *stats);
+
+/*
+ * Render::renderPathTracing on several GPUs at once: the reference fans the image
+ * out to 16 threads, one band of rows each, and joins them (src/Render.cpp:667-684).
+ * Here scenes[r] (the same scene uploaded to n_scenes devices with rtr_scene_create;
+ * handles must be distinct, devices may repeat) renders partition r of n_scenes --
+ * interleaved tiles of params->tile_cols columns (<=0: the widest tile of at most 8
+ * columns that gives every partition the same number of columns) -- on a host thread
+ * and stream of its own, with no traffic between devices while rendering.  Then each
+ * partition's framebuffer travels to scenes[0]'s device in ONE peer-to-peer copy on
+ * its own stream (xGMI links are point to point, so every device uses its own link
+ * to the root), and one kernel there puts the columns in image order.
+ * params->part_count must be 0 or 1.  rgb_out: the whole image, width*height*3
+ * floats in the reference's order (i*height + j), in host memory.  The image equals
+ * the single-device image bit for bit (for the same chunk_spp).  stats: counts are
+ * summed over partitions, kernel times are the slowest partition's.
+ */
+int rtr_render_pt_multi(rtr_scene *const *scenes, int32_t n_scenes, const rtr_camera *camera,
+                        const rtr_render_params *params, float *rgb_out, rtr_stats *stats);
+/* Same, leaving the image in DEVICE memory on scenes[0]'s device. */
+int rtr_render_pt_multi_device(rtr_scene *const *scenes, int32_t n_scenes,
+                               const rtr_camera *camera, const rtr_render_params *params,
+                               float *d_rgb_out, rtr_stats *stats);
 
 /* Number of columns a partition renders (so callers can size buffers), and the
  * global column index of each local column. */

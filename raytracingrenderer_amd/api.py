@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("n_columns", C.c_int32), ("mode", C.c_int32), ("ms_total", C.c_double),
                 ("ms_trace", C.c_double), ("ms_logic", C.c_double), ("ms_other", C.c_double),
                 ("trace_launches", C.c_uint64), ("ms_fused", C.c_double),
-                ("fused_launches", C.c_uint64)]
+                ("fused_launches", C.c_uint64), ("ms_gather", C.c_double),
+                ("n_devices", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -58,7 +59,8 @@ ABI_SYMBOLS = [
     "rtr_trace_closest", "rtr_trace_closest_device", "rtr_material_eval", "rtr_material_sample",
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
-    "rtr_create_photon_map_device",
+    "rtr_create_photon_map_device", "rtr_render_pt_multi",
+    "rtr_render_pt_multi_device",
 ]
 
 _hip = None
@@ -74,6 +76,7 @@ def hip_lib():
         L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
         L.rtr_last_error.restype = C.c_char_p
         L.rtr_device_count.argtypes = [_ip]
+        L.rtr_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rtr_scene_destroy.argtypes = [C.c_void_p]
         L.rtr_scene_destroy.restype = None
         L.rtr_trace_closest.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t, _ip, _fp, _fp, _fp]
@@ -94,6 +97,11 @@ def hip_lib():
                                     C.POINTER(Stats)]
         L.rtr_render_pt_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams),
                                            C.c_void_p, C.POINTER(Stats)]
+        L.rtr_render_pt_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera),
+                                          C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
+        L.rtr_render_pt_multi_device.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera),
+                                                 C.POINTER(RenderParams), C.c_void_p,
+                                                 C.POINTER(Stats)]
         L.rtr_partition_columns.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip]
         _hip = L
     return _hip
@@ -129,6 +137,7 @@ def host_lib():
         L.rtrh_set_node_box.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.rtrh_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp, _fp]
         L.rtrh_create_photon_map.restype = C.c_int64
+        L.rtrh_set_render_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
                                   C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
         _host = L
@@ -184,6 +193,7 @@ class HostScene:
         self._dev = None
 
     def close(self):
+        self.close_replicas()
         if self.h:
             self.L.rtrh_scene_free(self.h)
             self.h = None
@@ -407,10 +417,61 @@ class HostScene:
                "rtr_render_pt_device")
         return st
 
-    def render_via_host_api(self, W, H, spp, file=None, **kw):
-        """Render::renderPathTracing of the host library (optionally writes file.ppm)."""
+    def device_scenes(self, devices):
+        """One rtr_scene per entry of `devices` (uploads of this scene; a device may repeat)."""
+        key = tuple(int(d) for d in devices)
+        if getattr(self, "_replicas_key", None) != key:
+            self.close_replicas()
+            d = self.L.rtrh_scene_desc
+            d.restype = C.c_void_p
+            d.argtypes = [C.c_void_p]
+            desc = d(self.h)
+            if not desc:
+                self._herr("scene desc")
+            out = []
+            for dev in key:
+                h = C.c_void_p()
+                _check(hip_lib().rtr_scene_create(C.c_void_p(desc), dev, C.byref(h)), "rtr_scene_create")
+                out.append(h)
+            self._replicas, self._replicas_key = out, key
+        return self._replicas
+
+    def close_replicas(self):
+        for h in getattr(self, "_replicas", []):
+            hip_lib().rtr_scene_destroy(h)
+        self._replicas, self._replicas_key = [], None
+
+    def render_multi(self, W, H, spp, devices, d_ptr=None, **kw):
+        """rtr_render_pt_multi: the whole image (rgb[W*H,3], Stats) rendered as len(devices)
+        concurrent partitions; with d_ptr (device address on devices[0]) the image stays in
+        device memory and only Stats is returned."""
         p = self.make_params(W, H, spp, **kw)
-        ncol = len(partition_columns(W, p.part_index, p.part_count, p.tile_cols))
+        if "part_count" not in kw:
+            p.part_count = 0
+        scenes = self.device_scenes(devices)
+        arr = (C.c_void_p * len(scenes))(*[h.value for h in scenes])
+        st = Stats()
+        cam = self.camera_struct()
+        if d_ptr is not None:
+            _check(hip_lib().rtr_render_pt_multi_device(arr, len(scenes), C.byref(cam), C.byref(p),
+                                                        C.c_void_p(d_ptr), C.byref(st)),
+                   "rtr_render_pt_multi_device")
+            return st
+        rgb = np.zeros((W * H, 3), f32)
+        _check(hip_lib().rtr_render_pt_multi(arr, len(scenes), C.byref(cam), C.byref(p), _f(rgb),
+                                             C.byref(st)), "rtr_render_pt_multi")
+        return rgb, st
+
+    def render_via_host_api(self, W, H, spp, file=None, devices=None, **kw):
+        """Render::renderPathTracing of the host library (optionally writes file.ppm);
+        devices: RenderOptions::devices."""
+        p = self.make_params(W, H, spp, **kw)
+        devs = [int(d) for d in (devices or [])]
+        if self.L.rtrh_set_render_devices(self.h, (C.c_int * max(len(devs), 1))(*devs), len(devs)) != 0:
+            self._herr("set_render_devices")
+        if devs:
+            p.tile_cols = kw.get("tile_cols", 0)
+        ncol = W if devs else len(partition_columns(W, p.part_index, p.part_count, p.tile_cols))
         rgb = np.zeros((ncol * H, 3), f32)
         st = Stats()
         rc = self.L.rtrh_render(self.h, W, H, spp, file.encode() if file else None, C.byref(p),

@@ -3,11 +3,14 @@
 #include "../../include/rtr.h"
 #include "rtr_kernels.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace rtr;
@@ -53,8 +56,8 @@ struct Workspace {
   DevBuf<float4> pool[14];
   DevBuf<uint32_t> shade_list, queue;
   DevBuf<uint2> wave_res;  // wavefront loop: each wave's reserved, not yet dealt units
-  DevBuf<int32_t> cols;
   DevBuf<float> rgb;
+  DevBuf<float> gather;  // multi-device render: every partition's framebuffer, one after the other
   DevBuf<Counters> counters;
   DevBuf<BlockCounters> block_counters;
   Counters *host_counters = nullptr;             // pinned
@@ -64,7 +67,7 @@ struct Workspace {
     pix_dir.release(); pix_hit.release(); pc_pos.release(); pc_nrm.release(); pc_wi.release();
     partial.release();
     for (auto &b : pool) b.release();
-    shade_list.release(); queue.release(); cols.release(); rgb.release(); counters.release();
+    shade_list.release(); queue.release(); rgb.release(); gather.release(); counters.release();
     wave_res.release();
     block_counters.release();
     if (host_counters) (void)hipHostFree(host_counters);
@@ -100,6 +103,10 @@ struct rtr_scene {
   // different streams do not share one
   DevBuf<unsigned long long> trace_next;
   unsigned trace_next_turn = 0;
+  // one event per counter, recorded behind the launch that uses it: a counter is handed
+  // out again only once that launch has finished (the call waits if it has not)
+  hipEvent_t trace_done[64] = {};
+  bool trace_busy[64] = {};
   // photon emission: per-path counts of a batch, per-workgroup sums and offsets,
   // {photons in the batch, -}, number of paths the map took
   DevBuf<uint32_t> ph_counts, ph_paths_used;
@@ -112,7 +119,7 @@ struct rtr_scene {
 
 namespace {
 
-constexpr unsigned kTraceCounters = 64;
+constexpr unsigned kTraceCounters = 64;  // size of rtr_scene::trace_done
 constexpr int kFusedMaxNodes = 1 << 19;  // RTR_MODE_AUTO: largest tree the fused kernel is chosen for
 
 struct DeviceGuard {
@@ -147,12 +154,9 @@ float sqrt_threshold(float r) {
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// Launch shape and ray counter of a streaming traversal kernel over n rays: as many
-// workgroups as stay resident (never more than n needs), and the next of the scene's
-// rotating counters, zeroed on `stream` ahead of the launch.
+// Resident workgroups of a persistent kernel on the scene's device.
 template <class Kernel>
-int stream_launch(rtr_scene *s, Kernel kernel, int &cached_grid, size_t n, hipStream_t stream,
-                  unsigned &grid, unsigned long long *&next) {
+int resident_grid(rtr_scene *s, Kernel kernel, int &cached_grid) {
   if (cached_grid == 0) {
     int per_cu = 0, cus = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
@@ -160,11 +164,37 @@ int stream_launch(rtr_scene *s, Kernel kernel, int &cached_grid, size_t n, hipSt
     if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
     cached_grid = per_cu * cus;
   }
+  return RTR_OK;
+}
+
+// Launch shape and ray counter of a streaming traversal kernel over n rays: as many
+// workgroups as stay resident (never more than n needs), and the next of the scene's
+// rotating counters, zeroed on `stream` ahead of the launch.  The counter's previous
+// launch (kTraceCounters calls ago, possibly on another stream) must be over before it
+// is zeroed again: its event says so, and the call waits for it otherwise.  After the
+// launch the caller records the event again with stream_launched().
+template <class Kernel>
+int stream_launch(rtr_scene *s, Kernel kernel, int &cached_grid, size_t n, hipStream_t stream,
+                  unsigned &grid, unsigned long long *&next, unsigned &turn) {
+  if (int rc = resident_grid(s, kernel, cached_grid)) return rc;
   HIP_TRY(s->trace_next.reserve(kTraceCounters));
-  next = s->trace_next.ptr + (s->trace_next_turn++ % kTraceCounters);
+  turn = s->trace_next_turn++ % kTraceCounters;
+  if (!s->trace_done[turn])
+    HIP_TRY(hipEventCreateWithFlags(&s->trace_done[turn], hipEventDisableTiming));
+  if (s->trace_busy[turn]) {
+    HIP_TRY(hipEventSynchronize(s->trace_done[turn]));
+    s->trace_busy[turn] = false;
+  }
+  next = s->trace_next.ptr + turn;
   HIP_TRY(hipMemsetAsync(next, 0, sizeof(*next), stream));
   grid = (unsigned)cached_grid;
   if ((uint64_t)grid * kBlock > n) grid = blocks_for(n);
+  return RTR_OK;
+}
+
+int stream_launched(rtr_scene *s, unsigned turn, hipStream_t stream) {
+  HIP_TRY(hipEventRecord(s->trace_done[turn], stream));
+  s->trace_busy[turn] = true;
   return RTR_OK;
 }
 
@@ -203,6 +233,222 @@ void partition_columns(int W, int part_index, int part_count, int tile_cols,
 int check_xyz(const float *const p[3], const char *name) {
   if (!p[0] || !p[1] || !p[2]) return fail(RTR_ERR_INVALID, std::string(name) + " has a null axis");
   return RTR_OK;
+}
+
+// Number of image columns partition part_index of part_count renders (see ColumnMap).
+int count_columns(int W, int part_index, int part_count, int tile_cols) {
+  if (part_count <= 1) return W;
+  const int n_tiles = (W + tile_cols - 1) / tile_cols;
+  if (part_index >= n_tiles) return 0;
+  const int mine = (n_tiles - part_index + part_count - 1) / part_count;
+  int n = mine * tile_cols;
+  if ((n_tiles - 1) % part_count == part_index) n -= n_tiles * tile_cols - W;  // the narrow last tile
+  return n;
+}
+
+// Widest tile of at most 8 columns that deals every partition the same number of columns;
+// 8 if there is none.
+int balanced_tile_cols(int W, int part_count) {
+  if (part_count <= 1) return 8;
+  for (int t = 8; t >= 1; t--)
+    if (W % t == 0 && (W / t) % part_count == 0) return t;
+  return 8;
+}
+
+// Event pairs around kernels (rtr_render_params.profile); destroyed with the object, so
+// no return path of a render leaks them.
+struct EventSpans {
+  struct Span { hipEvent_t a, b; int kind; bool ok; };
+  bool on = false;
+  std::vector<Span> live, idle;
+  double ms[4] = {0, 0, 0, 0};  // 0 trace, 1 logic, 2 other, 3 fused
+  ~EventSpans() {
+    for (auto *v : {&live, &idle})
+      for (Span &sp : *v) {
+        if (sp.a) (void)hipEventDestroy(sp.a);
+        if (sp.b) (void)hipEventDestroy(sp.b);
+      }
+  }
+  // Only after the stream the spans were recorded on has been synchronised.
+  void harvest() {
+    for (Span &sp : live) {
+      float t = 0;
+      if (sp.ok && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) ms[sp.kind] += t;
+      idle.push_back(sp);
+    }
+    live.clear();
+  }
+  template <class Launch>
+  hipError_t run(hipStream_t st, int kind, Launch &&launch) {
+    Span sp{nullptr, nullptr, kind, false};
+    if (on) {
+      if (!idle.empty()) {
+        sp = idle.back();
+        idle.pop_back();
+        sp.kind = kind;
+      } else {
+        hipError_t e = hipEventCreate(&sp.a);
+        if (e == hipSuccess) e = hipEventCreate(&sp.b);
+        if (e != hipSuccess) {
+          if (sp.a) (void)hipEventDestroy(sp.a);
+          return e;
+        }
+      }
+      sp.ok = hipEventRecord(sp.a, st) == hipSuccess;
+    }
+    launch();
+    hipError_t e = hipGetLastError();
+    if (on) {
+      sp.ok = (hipEventRecord(sp.b, st) == hipSuccess) && sp.ok;  // a failed record: the span is not counted
+      live.push_back(sp);
+    }
+    return e;
+  }
+};
+constexpr int kSpanTrace = 0, kSpanLogic = 1, kSpanOther = 2, kSpanFused = 3;
+
+// What a render call asks for, checked and with the defaults filled in.
+struct RenderPlan {
+  RenderArgs a;
+  ColumnMap cm;
+  CameraSetup cs;
+  size_t units;  // n_pix * n_chunks: partial sums
+  bool fused;
+};
+
+// Checks shared by every render entry point; fills `plan`.  unit_budget bounds
+// n_pix * n_chunks when the caller leaves chunk_spp to the library.
+int plan_render(const rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm,
+                size_t unit_budget, RenderPlan &plan) {
+  if (prm->width <= 0 || prm->height <= 0 || prm->spp <= 0)
+    return fail(RTR_ERR_INVALID, "width, height and spp must be positive");
+  if ((int64_t)prm->width * prm->height > 0x7fffffff) return fail(RTR_ERR_INVALID, "image too large");
+  if (prm->part_count > 1 && (prm->part_index < 0 || prm->part_index >= prm->part_count))
+    return fail(RTR_ERR_INVALID, "part_index out of range");
+  if (prm->mode < 0 || prm->mode > 2) return fail(RTR_ERR_INVALID, "mode must be 0, 1 or 2");
+  RenderArgs &a = plan.a;
+  a = RenderArgs{};
+  plan.cm.part_count = prm->part_count > 1 ? prm->part_count : 1;
+  plan.cm.part_index = prm->part_count > 1 ? prm->part_index : 0;
+  plan.cm.tile_cols = prm->tile_cols > 0 ? prm->tile_cols : 8;
+  a.W = prm->width; a.H = prm->height; a.spp = prm->spp;
+  a.n_cols = count_columns(a.W, plan.cm.part_index, plan.cm.part_count, plan.cm.tile_cols);
+  a.n_pix = a.n_cols * a.H;
+  a.seed = prm->seed;
+  a.max_depth = prm->max_depth > 0 ? prm->max_depth : 0;
+  a.rr = prm->rr_prob > 0 ? prm->rr_prob : 0.6f;
+  if (prm->chunk_spp > 0) {
+    a.chunk_spp = prm->chunk_spp;
+  } else {
+    // default: up to 128 partial sums per pixel -- units small enough that the last one a
+    // lane works on is a small share of its run, also when the image is split over 8
+    // GPUs -- but no more units than the budget (large images get fewer, longer chunks)
+    size_t chunks = a.n_pix > 0 ? unit_budget / (size_t)a.n_pix : 1;
+    chunks = std::min<size_t>(std::max<size_t>(chunks, 1), 128);
+    a.chunk_spp = (int)((prm->spp + chunks - 1) / chunks);
+  }
+  if (a.chunk_spp > a.spp) a.chunk_spp = a.spp;
+  a.n_chunks = (a.spp + a.chunk_spp - 1) / a.chunk_spp;
+  plan.units = (size_t)a.n_pix * a.n_chunks;
+  if (plan.units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
+  plan.cs = camera_setup(*cam, a.H);
+  // one persistent kernel with path state in registers, or the wavefront loop over a pool
+  // of paths in HBM (measured on height-field meshes, fused kernel against wavefront loop,
+  // Msamples/s: 6 K nodes 1255 : 708 and 360 K nodes 674 : 545 at 64 spp; 160 K nodes
+  // 811 : 735, 360 K nodes 691 : 672 and 2 M nodes 401 : 460 at 256 spp)
+  plan.fused = prm->mode == RTR_MODE_FUSED ||
+               (prm->mode == RTR_MODE_AUTO && (s->lds_geometry || s->ds.n_nodes <= kFusedMaxNodes));
+  return RTR_OK;
+}
+
+// Device memory every render needs, whichever way the sampling loop runs.
+struct RenderBuffers {
+  float4 *pix_dir, *pix_hit, *partial;
+  PixelCache pc;
+  uint32_t *shade_list;
+  Counters *cnt;
+};
+
+// ray generation, primary rays, first vertex of every pixel
+int enqueue_front(rtr_scene *s, const RenderPlan &pl, const RenderBuffers &b, hipStream_t st,
+                  EventSpans &ev) {
+  const RenderArgs &a = pl.a;
+  HIP_TRY(hipMemsetAsync(b.cnt, 0, sizeof(Counters), st));
+  HIP_TRY(ev.run(st, kSpanOther, [&] {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, pl.cs, pl.cm, b.pix_dir);
+  }));
+  HIP_TRY(ev.run(st, kSpanTrace, [&] {
+    if (s->lds_geometry)
+      hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, s->ds,
+                         pl.cs, b.pix_dir, a.n_pix, b.pix_hit);
+    else
+      hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, s->ds,
+                         pl.cs, b.pix_dir, a.n_pix, b.pix_hit);
+  }));
+  HIP_TRY(ev.run(st, kSpanOther, [&] {
+    hipLaunchKernelGGL(k_classify, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, s->ds, s->mats.ptr,
+                       pl.cs, b.pix_dir, b.pix_hit, b.pc, b.shade_list, b.cnt, b.partial);
+  }));
+  return RTR_OK;
+}
+
+int fused_grid(rtr_scene *s) {
+  if (s->lds_geometry) return resident_grid(s, k_render_fused<true>, s->fused_grid);
+  return resident_grid(s, k_render_fused<false>, s->fused_grid);
+}
+
+// The whole sampling loop as one launch.  The kernel reads the number of pixels that need
+// sampling from the classification kernel's counter on the device, so nothing waits
+// between the two.  s->fused_grid must be known (fused_grid()).
+int enqueue_fused(rtr_scene *s, const RenderPlan &pl, const RenderBuffers &b, hipStream_t st,
+                  EventSpans &ev) {
+  const RenderArgs &a = pl.a;
+  // as many workgroups as the device keeps resident at once; every lane then works
+  // through its share of the units
+  unsigned grid = (unsigned)s->fused_grid;
+  if ((uint64_t)grid * kBlock > pl.units) grid = (unsigned)((pl.units + kBlock - 1) / kBlock);
+  HIP_TRY(ev.run(st, kSpanFused, [&] {
+    if (s->lds_geometry)
+      hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, b.pc,
+                         b.shade_list, b.partial, b.cnt);
+    else
+      hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, b.pc,
+                         b.shade_list, b.partial, b.cnt);
+  }));
+  return RTR_OK;
+}
+
+int enqueue_resolve(const RenderPlan &pl, const RenderBuffers &b, float *d_rgb, hipStream_t st,
+                    EventSpans &ev) {
+  HIP_TRY(ev.run(st, kSpanOther, [&] {
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(pl.a.n_pix)), dim3(kBlock), 0, st, pl.a, b.partial, d_rgb);
+  }));
+  return RTR_OK;
+}
+
+}  // namespace
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+// pairs of devices whose peer access has been switched on (or found impossible)
+std::mutex g_peer_mutex;
+bool g_peer_tried[kMaxDevices][kMaxDevices] = {};
+void enable_peer_access(int a, int b) {
+  if (a == b || a < 0 || b < 0 || a >= kMaxDevices || b >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_peer_mutex);
+  if (g_peer_tried[a][b]) return;
+  g_peer_tried[a][b] = g_peer_tried[b][a] = true;
+  // best effort: without it hipMemcpyPeerAsync still works, staged through the host
+  int can = 0;
+  for (int k = 0; k < 2; k++) {
+    const int from = k ? b : a, to = k ? a : b;
+    if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can && hipSetDevice(from) == hipSuccess)
+      (void)hipDeviceEnablePeerAccess(to, 0);
+  }
+  (void)hipGetLastError();  // "already enabled" is not an error worth keeping
 }
 
 }  // namespace
@@ -549,6 +795,8 @@ void rtr_scene_destroy(rtr_scene *s) {
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();
   s->trace_next.release();
+  for (hipEvent_t e : s->trace_done)
+    if (e) (void)hipEventDestroy(e);
   s->ph_counts.release(); s->ph_paths_used.release(); s->ph_sums.release(); s->ph_offs.release();
   s->ph_total.release();
   for (auto &b : s->io_f) b.release();
@@ -570,12 +818,14 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
     hipLaunchKernelGGL(k_trace_api<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        s->ds, d_org, d_dir, n, d_prim, d_t, d_pos, d_nrm);
   } else {
-    unsigned grid = 0;
+    unsigned grid = 0, turn = 0;
     unsigned long long *next = nullptr;
-    int rc = stream_launch(s, k_trace_api_stream, s->stream_grid, n, (hipStream_t)stream, grid, next);
+    int rc = stream_launch(s, k_trace_api_stream, s->stream_grid, n, (hipStream_t)stream, grid, next, turn);
     if (rc) return rc;
     hipLaunchKernelGGL(k_trace_api_stream, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s->ds,
                        d_org, d_dir, (unsigned long long)n, d_prim, d_t, d_pos, d_nrm, next);
+    HIP_TRY(hipGetLastError());
+    return stream_launched(s, turn, (hipStream_t)stream);
   }
   HIP_TRY(hipGetLastError());
   return RTR_OK;
@@ -720,13 +970,15 @@ int rtr_check_connectable(rtr_scene *s, const float *a_xyz, const float *b_xyz, 
     hipLaunchKernelGGL(k_check_connectable<true>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream,
                        s->ds, (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr, count, out);
   } else {
-    unsigned grid = 0;
+    unsigned grid = 0, turn = 0;
     unsigned long long *next = nullptr;
-    int rc = stream_launch(s, k_check_connectable_stream, s->connect_grid, count, s->stream, grid, next);
+    int rc = stream_launch(s, k_check_connectable_stream, s->connect_grid, count, s->stream, grid, next, turn);
     if (rc) return rc;
     hipLaunchKernelGGL(k_check_connectable_stream, dim3(grid), dim3(kBlock), 0, s->stream, s->ds,
                        (const float *)s->io_f[0].ptr, (const float *)s->io_f[1].ptr,
                        (unsigned long long)count, out, next);
+    HIP_TRY(hipGetLastError());
+    if ((rc = stream_launched(s, turn, s->stream))) return rc;
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(connected, out, count, hipMemcpyDeviceToHost, s->stream));
@@ -824,6 +1076,10 @@ int rtr_partition_columns(int32_t width, int32_t part_index, int32_t part_count,
     return fail(RTR_ERR_INVALID, "bad partition");
   std::vector<int32_t> cols;
   partition_columns(width, part_index, part_count, tile_cols, cols);
+  // the renderer never builds this list: its kernels map local columns to image columns
+  // by formula (ColumnMap), and the count comes from count_columns()
+  if ((int)cols.size() != count_columns(width, part_index, part_count, tile_cols > 0 ? tile_cols : 8))
+    return fail(RTR_ERR_DEVICE, "internal: column count and column list disagree");
   if (n_columns) *n_columns = (int32_t)cols.size();
   if (columns) memcpy(columns, cols.data(), cols.size() * sizeof(int32_t));
   return RTR_OK;
@@ -832,35 +1088,18 @@ int rtr_partition_columns(int32_t width, int32_t part_index, int32_t part_count,
 int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm,
                          float *d_rgb, rtr_stats *stats) {
   if (!s || !cam || !prm || !d_rgb) return fail(RTR_ERR_INVALID, "null argument");
-  if (prm->width <= 0 || prm->height <= 0 || prm->spp <= 0)
-    return fail(RTR_ERR_INVALID, "width, height and spp must be positive");
-  if ((int64_t)prm->width * prm->height > 0x7fffffff)
-    return fail(RTR_ERR_INVALID, "image too large");
-  if (prm->part_count > 1 && (prm->part_index < 0 || prm->part_index >= prm->part_count))
-    return fail(RTR_ERR_INVALID, "part_index out of range");
+  if (stats) memset(stats, 0, sizeof(*stats));
   auto t_start = std::chrono::steady_clock::now();
+  RenderPlan pl;
+  // unit budget: 2^27 partial sums (2 GiB); 128 per pixel up to about 1000 x 1000 pixels
+  if (int rc = plan_render(s, cam, prm, (size_t)1 << 27, pl)) return rc;
+  RenderArgs &a = pl.a;
+  if (a.n_pix == 0) return RTR_OK;
   DeviceGuard guard(s->device);
   Workspace &ws = s->ws;
   hipStream_t st = s->stream;
-
-  std::vector<int32_t> cols;
-  partition_columns(prm->width, prm->part_index, prm->part_count, prm->tile_cols, cols);
-  RenderArgs a{};
-  a.W = prm->width; a.H = prm->height; a.spp = prm->spp;
-  a.n_cols = (int)cols.size();
-  a.n_pix = a.n_cols * a.H;
-  a.seed = prm->seed;
-  a.max_depth = prm->max_depth > 0 ? prm->max_depth : 0;
-  a.rr = prm->rr_prob > 0 ? prm->rr_prob : 0.6f;
-  // default: 128 partial sums per pixel -- units small enough that the last one a lane
-  // works on is a small share of its run, also when the image is split over 8 GPUs
-  a.chunk_spp = prm->chunk_spp > 0 ? prm->chunk_spp : (prm->spp + 127) / 128;
-  if (a.chunk_spp > a.spp) a.chunk_spp = a.spp;
-  a.n_chunks = (a.spp + a.chunk_spp - 1) / a.chunk_spp;
-  if (stats) memset(stats, 0, sizeof(*stats));
-  if (a.n_pix == 0) return RTR_OK;
-  size_t max_units = (size_t)a.n_pix * a.n_chunks;
-  if (max_units > 0xfffffff0ull) return fail(RTR_ERR_INVALID, "too many work units; raise chunk_spp");
+  const size_t max_units = pl.units;
+  const bool fused = pl.fused;
   // upper bound of the pool; the exact size follows from the number of pixels
   // that need sampling (known after k_classify)
   // (measured: 2^21 slots is best where the scene sits in LDS, 2^22 where traversal reads it
@@ -872,9 +1111,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   if (pool > max_units) pool = max_units;
   pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
   if (pool > 0x7fffffffu) return fail(RTR_ERR_INVALID, "pool too large");
-  CameraSetup cs = camera_setup(*cam, a.H);
 
-  HIP_TRY(ws.cols.reserve(cols.size()));
   HIP_TRY(ws.pix_dir.reserve(a.n_pix));
   HIP_TRY(ws.pix_hit.reserve(a.n_pix));
   HIP_TRY(ws.pc_pos.reserve(a.n_pix));
@@ -882,107 +1119,52 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   HIP_TRY(ws.pc_wi.reserve(a.n_pix));
   HIP_TRY(ws.shade_list.reserve(a.n_pix));
   HIP_TRY(ws.partial.reserve(max_units));
-  // mode: one persistent kernel with path state in registers (scenes whose traversal
-  // needs no per-wave queues), or the wavefront loop over a pool of paths in HBM
-  if (prm->mode < 0 || prm->mode > 2) return fail(RTR_ERR_INVALID, "mode must be 0, 1 or 2");
-  // (measured on height-field meshes, fused kernel against wavefront loop, Msamples/s:
-  // 6 K nodes 1255 : 708 and 360 K nodes 674 : 545 at 64 spp; 160 K nodes 811 : 735,
-  // 360 K nodes 691 : 672 and 2 M nodes 401 : 460 at 256 spp)
-  const bool fused = prm->mode == RTR_MODE_FUSED ||
-                     (prm->mode == RTR_MODE_AUTO && (s->lds_geometry || s->ds.n_nodes <= kFusedMaxNodes));
-  if (fused) pool = kLogicBlock * kGroup;  // the wavefront buffers are not used
-  for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
-  HIP_TRY(ws.queue.reserve(2 * pool));  // one segment of kSegment entries per k_logic workgroup
-  HIP_TRY(ws.wave_res.reserve(pool / 64));
   HIP_TRY(ws.counters.reserve(1));
   if (!ws.host_counters) HIP_TRY(hipHostMalloc((void **)&ws.host_counters, sizeof(Counters)));
-  size_t n_blocks = pool / kLogicBlock;  // capacity; the launch uses what the schedule needs
-  HIP_TRY(ws.block_counters.reserve(n_blocks));
-  if (ws.host_block_cap < n_blocks) {
-    if (ws.host_block_counters) (void)hipHostFree(ws.host_block_counters);
-    ws.host_block_counters = nullptr;
-    ws.host_block_cap = 0;
-    HIP_TRY(hipHostMalloc((void **)&ws.host_block_counters, n_blocks * sizeof(BlockCounters)));
-    ws.host_block_cap = n_blocks;
+  size_t n_blocks = 0;
+  if (!fused) {
+    for (auto &b : ws.pool) HIP_TRY(b.reserve(pool));
+    HIP_TRY(ws.queue.reserve(2 * pool));  // one segment of kSegment entries per k_logic workgroup
+    HIP_TRY(ws.wave_res.reserve(pool / 64));
+    n_blocks = pool / kLogicBlock;  // capacity; the launch uses what the schedule needs
+    HIP_TRY(ws.block_counters.reserve(n_blocks));
+    if (ws.host_block_cap < n_blocks) {
+      if (ws.host_block_counters) (void)hipHostFree(ws.host_block_counters);
+      ws.host_block_counters = nullptr;
+      ws.host_block_cap = 0;
+      HIP_TRY(hipHostMalloc((void **)&ws.host_block_counters, n_blocks * sizeof(BlockCounters)));
+      ws.host_block_cap = n_blocks;
+    }
+  } else {
+    if (int rc = fused_grid(s)) return rc;
   }
 
-  PixelCache pc{ws.pc_pos.ptr, ws.pc_nrm.ptr, ws.pc_wi.ptr};
+  RenderBuffers rb{ws.pix_dir.ptr, ws.pix_hit.ptr, ws.partial.ptr,
+                   PixelCache{ws.pc_pos.ptr, ws.pc_nrm.ptr, ws.pc_wi.ptr}, ws.shade_list.ptr,
+                   ws.counters.ptr};
+  const PixelCache pc = rb.pc;
   PathPool pp{ws.pool[0].ptr, ws.pool[1].ptr, ws.pool[2].ptr, ws.pool[3].ptr, ws.pool[4].ptr,
               ws.pool[5].ptr, ws.pool[6].ptr, ws.pool[7].ptr, ws.pool[8].ptr, ws.pool[9].ptr,
               ws.pool[10].ptr, ws.pool[11].ptr, ws.pool[12].ptr, ws.pool[13].ptr};
-  Counters *cnt = ws.counters.ptr;
+  Counters *cnt = rb.cnt;
   BlockCounters *bc = ws.block_counters.ptr;
 
   // profile=1: every kernel is bracketed by a pair of events on the launch stream;
   // elapsed times are read back only after a synchronisation the render needs
   // anyway, so profiling adds event records but no extra waits.
-  const bool prof = prm->profile != 0;
-  struct Span { hipEvent_t a, b; int kind; };
-  std::vector<Span> spans;      // recorded, not yet read
-  std::vector<Span> free_spans; // reusable
-  double ms_kind[4] = {0, 0, 0, 0};  // 0 trace, 1 logic, 2 other, 3 fused
-  auto harvest = [&]() {
-    for (Span &sp : spans) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) ms_kind[sp.kind] += ms;
-      free_spans.push_back(sp);
-    }
-    spans.clear();
-  };
-  auto timed_on = [&](hipStream_t st, int kind, auto &&launch) -> hipError_t {
-    Span sp{nullptr, nullptr, kind};
-    if (prof) {
-      if (!free_spans.empty()) {
-        sp = free_spans.back();
-        sp.kind = kind;
-        free_spans.pop_back();
-      } else {
-        hipError_t e = hipEventCreate(&sp.a);
-        if (e == hipSuccess) e = hipEventCreate(&sp.b);
-        if (e != hipSuccess) return e;
-      }
-      (void)hipEventRecord(sp.a, st);
-    }
-    launch();
-    hipError_t e = hipGetLastError();
-    if (prof) {
-      (void)hipEventRecord(sp.b, st);
-      spans.push_back(sp);
-    }
-    return e;
-  };
-  auto timed = [&](int kind, auto &&launch) -> hipError_t { return timed_on(st, kind, launch); };
-  const int kTrace = 0, kLogic = 1, kOther = 2, kFused = 3;
+  EventSpans ev;
+  ev.on = prm->profile != 0;
 
-  HIP_TRY(hipMemcpyAsync(ws.cols.ptr, cols.data(), cols.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), st));
-  uint64_t trace_launches = 0, fused_launches = 0;
-  HIP_TRY(timed(kOther, [&] {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, cs,
-                       ws.cols.ptr, ws.pix_dir.ptr);
-  }));
-  HIP_TRY(timed(kTrace, [&] {
-    if (s->lds_geometry)
-      hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st,
-                         s->ds, cs, ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
-    else
-      hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st,
-                         s->ds, cs, ws.pix_dir.ptr, a.n_pix, ws.pix_hit.ptr);
-  }));
-  trace_launches++;
-  HIP_TRY(timed(kOther, [&] {
-    hipLaunchKernelGGL(k_classify, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a, s->ds,
-                       s->mats.ptr, cs, ws.pix_dir.ptr, ws.pix_hit.ptr, pc, ws.shade_list.ptr, cnt,
-                       ws.partial.ptr);
-  }));
+  uint64_t trace_launches = 1, fused_launches = 0;  // 1: the primary rays
+  if (int rc = enqueue_front(s, pl, rb, st, ev)) return rc;
   // The wavefront loop sizes its pool and its unit schedule from the number of
   // pixels that need sampling; the fused kernel reads that counter on the device, so
   // nothing waits between classification and sampling.
-  uint64_t n_units = (uint64_t)a.n_pix * a.n_chunks;  // fused mode: an upper bound
+  uint64_t n_units = max_units;  // fused mode: an upper bound
   if (!fused) {
     HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    harvest();
+    ev.harvest();
     n_units = (uint64_t)ws.host_counters->n_shade * a.n_chunks;
     a.n_shade = ws.host_counters->n_shade;
     a.n_units = (uint32_t)n_units;
@@ -999,30 +1181,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
 
   uint64_t iters = 0, total_rays = 0, total_vertices = 0;
   if (n_units > 0 && fused) {
-    // as many workgroups as the device keeps resident at once; every lane then
-    // works through its share of the units
-    if (s->fused_grid == 0) {
-      int per_cu = 0, cus = 0;
-      if (s->lds_geometry)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_fused<true>, kBlock, 0));
-      else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_fused<false>, kBlock, 0));
-      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
-      if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
-      s->fused_grid = per_cu * cus;
-    }
-    unsigned grid = (unsigned)s->fused_grid;
-    if ((uint64_t)grid * kBlock > n_units) grid = (unsigned)((n_units + kBlock - 1) / kBlock);
-    HIP_TRY(timed(kFused, [&] {
-      if (s->lds_geometry)
-        hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                           s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, pc,
-                           ws.shade_list.ptr, ws.partial.ptr, cnt);
-      else
-        hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                           s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, pc,
-                           ws.shade_list.ptr, ws.partial.ptr, cnt);
-    }));
+    if (int rc = enqueue_fused(s, pl, rb, st, ev)) return rc;
     fused_launches = 1;
     iters = 1;
   } else if (n_units > 0) {
@@ -1036,13 +1195,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     hipStream_t streams[2] = {st, s->stream2};
     unsigned queue_grid = 0;
     if (!s->lds_geometry) {
-      if (s->queue_grid == 0) {
-        int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_queue_stream, kBlock, 0));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
-        if (per_cu < 1 || cus < 1) return fail(RTR_ERR_DEVICE, "occupancy query failed");
-        s->queue_grid = per_cu * cus;
-      }
+      if (int rc = resident_grid(s, k_trace_queue_stream, s->queue_grid)) return rc;
       // no more waves than there could be 64-ray batches in a launch
       const size_t most = (grp_begin[1] * kGroup * kSegment + kBlock - 1) / kBlock;
       queue_grid = (unsigned)std::min<size_t>((size_t)s->queue_grid, std::max<size_t>(most, 1));
@@ -1053,12 +1206,12 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
         a.first = iters == 0 ? 1 : 0;
         for (int h = 0; h < n_halves; h++) {
           const unsigned g0 = (unsigned)grp_begin[h], ng = (unsigned)(grp_begin[h + 1] - grp_begin[h]);
-          HIP_TRY(timed_on(streams[h], kLogic, [&] {
+          HIP_TRY(ev.run(streams[h], kSpanLogic, [&] {
             hipLaunchKernelGGL(k_logic, dim3(ng * kGroup), dim3(kLogicBlock), 0, streams[h], a, s->ds,
                                s->dl, s->mats.ptr, pc, pp, ws.shade_list.ptr, ws.queue.ptr, bc,
                                ws.partial.ptr, cnt, ws.wave_res.ptr, parity, (int)(g0 * kGroup));
           }));
-          HIP_TRY(timed_on(streams[h], kTrace, [&] {
+          HIP_TRY(ev.run(streams[h], kSpanTrace, [&] {
             if (s->lds_geometry)
               hipLaunchKernelGGL(k_trace_queue<true>, dim3(ng * kGroupParts), dim3(kBlock), 0,
                                  streams[h], s->ds, pp, ws.queue.ptr, bc, parity, g0);
@@ -1074,7 +1227,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       HIP_TRY(hipMemcpyAsync(ws.host_block_counters, bc, n_blocks * sizeof(BlockCounters),
                              hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      harvest();
+      ev.harvest();
       uint64_t done = 0;
       total_rays = total_vertices = 0;
       for (size_t k = 0; k < n_blocks; k++) {
@@ -1086,20 +1239,13 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
       if (iters > (uint64_t)1 << 40) return fail(RTR_ERR_DEVICE, "render did not terminate");
     }
   }
-  HIP_TRY(timed(kOther, [&] {
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(a.n_pix)), dim3(kBlock), 0, st, a,
-                       ws.partial.ptr, d_rgb);
-  }));
+  if (int rc = enqueue_resolve(pl, rb, d_rgb, st, ev)) return rc;
   if (fused) HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  harvest();
+  ev.harvest();
   if (fused) {
     total_rays = ws.host_counters->rays;
     total_vertices = ws.host_counters->vertices;
-  }
-  for (Span &sp : free_spans) {
-    (void)hipEventDestroy(sp.a);
-    (void)hipEventDestroy(sp.b);
   }
   if (stats) {
     stats->samples = (uint64_t)a.n_pix * a.spp;
@@ -1110,12 +1256,13 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     stats->pool_size = fused ? 0 : a.pool;
     stats->mode = fused ? RTR_MODE_FUSED : RTR_MODE_WAVEFRONT;
     stats->n_columns = a.n_cols;
-    stats->ms_trace = ms_kind[kTrace];
-    stats->ms_logic = ms_kind[kLogic];
-    stats->ms_other = ms_kind[kOther];
+    stats->ms_trace = ev.ms[kSpanTrace];
+    stats->ms_logic = ev.ms[kSpanLogic];
+    stats->ms_other = ev.ms[kSpanOther];
     stats->trace_launches = trace_launches;
-    stats->ms_fused = ms_kind[kFused];
+    stats->ms_fused = ev.ms[kSpanFused];
     stats->fused_launches = fused_launches;
+    stats->n_devices = 1;
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   }
@@ -1125,11 +1272,11 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
 int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm, float *rgb,
                   rtr_stats *stats) {
   if (!s || !cam || !prm || !rgb) return fail(RTR_ERR_INVALID, "null argument");
-  if (prm->width <= 0 || prm->height <= 0) return fail(RTR_ERR_INVALID, "bad image size");
+  if (stats) memset(stats, 0, sizeof(*stats));
   auto t_start = std::chrono::steady_clock::now();
-  std::vector<int32_t> cols;
-  partition_columns(prm->width, prm->part_index, prm->part_count, prm->tile_cols, cols);
-  size_t n = (size_t)cols.size() * prm->height * 3;
+  RenderPlan pl;
+  if (int rc = plan_render(s, cam, prm, (size_t)1 << 27, pl)) return rc;
+  const size_t n = (size_t)pl.a.n_pix * 3;
   if (n == 0) return RTR_OK;
   DeviceGuard guard(s->device);
   HIP_TRY(s->ws.rgb.reserve(n));
@@ -1140,6 +1287,162 @@ int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return RTR_OK;
+}
+
+// One host thread per scene, as the reference's renderer has one per band of rows
+// (src/Render.cpp:667-684); the join is followed by the only traffic between devices.
+static int render_multi(rtr_scene *const *scenes, int32_t n_scenes, const rtr_camera *cam,
+                        const rtr_render_params *prm, float *d_rgb, float *h_rgb, rtr_stats *stats) {
+  if (!scenes || !cam || !prm || (!d_rgb && !h_rgb)) return fail(RTR_ERR_INVALID, "null argument");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_scenes < 1 || n_scenes > kMaxParts) return fail(RTR_ERR_INVALID, "n_scenes must be 1..64");
+  for (int r = 0; r < n_scenes; r++) {
+    if (!scenes[r]) return fail(RTR_ERR_INVALID, "null scene handle");
+    for (int q = 0; q < r; q++)
+      if (scenes[q] == scenes[r])
+        return fail(RTR_ERR_INVALID, "the same scene handle twice (a handle serves one thread at a time)");
+  }
+  if (prm->part_count > 1) return fail(RTR_ERR_INVALID, "part_count must be 0 or 1: this call partitions the image itself");
+  auto t_start = std::chrono::steady_clock::now();
+  const int R = n_scenes;
+  rtr_scene *root = scenes[0];
+  rtr_render_params base = *prm;
+  base.part_count = R;
+  base.tile_cols = prm->tile_cols > 0 ? prm->tile_cols : balanced_tile_cols(prm->width, R);
+  // validate once, on the calling thread, so that argument errors are plain errors
+  {
+    RenderPlan pl;
+    base.part_index = 0;
+    if (int rc = plan_render(root, cam, &base, (size_t)1 << 27, pl)) return rc;
+  }
+  const int W = prm->width, H = prm->height;
+  PartOffsets po{};
+  std::vector<int> n_cols(R);
+  size_t total = 0;
+  for (int r = 0; r < R; r++) {
+    n_cols[r] = count_columns(W, r, R, base.tile_cols);
+    po.off[r] = total;
+    total += (size_t)n_cols[r] * H * 3;
+  }
+  if (total != (size_t)W * H * 3) return fail(RTR_ERR_DEVICE, "internal: partitions do not cover the image");
+
+  // device 0 of the call holds every partition's framebuffer, then the whole image
+  {
+    DeviceGuard guard(root->device);
+    HIP_TRY(root->ws.gather.reserve(total));
+    if (!d_rgb) HIP_TRY(root->ws.rgb.reserve(total));
+    for (int r = 1; r < R; r++) enable_peer_access(root->device, scenes[r]->device);
+  }
+  float *const gathered = root->ws.gather.ptr;
+  float *const image = d_rgb ? d_rgb : root->ws.rgb.ptr;
+
+  struct Rank {
+    int rc = RTR_OK;
+    std::string error;
+    rtr_stats st{};
+    hipEvent_t arrived = nullptr;
+  };
+  std::vector<Rank> ranks(R);
+  auto work = [&](int r) {
+    Rank &me = ranks[r];
+    rtr_scene *s = scenes[r];
+    auto bail = [&](int rc) {
+      me.rc = rc;
+      me.error = g_error;
+    };
+    rtr_render_params p = base;
+    p.part_index = r;
+    if (n_cols[r] == 0) return;
+    const size_t n = (size_t)n_cols[r] * H * 3;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return bail(fail(RTR_ERR_DEVICE, "hipSetDevice failed"));
+    // rank 0 renders straight into its place; the others into their own framebuffer,
+    // which then travels to device 0 in one copy on the rank's own stream
+    float *dst = gathered + po.off[r];
+    if (r != 0) {
+      hipError_t e = s->ws.rgb.reserve(n);
+      if (e != hipSuccess) return bail(fail(RTR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)));
+      dst = s->ws.rgb.ptr;
+    }
+    if (int rc = rtr_render_pt_device(s, cam, &p, dst, &me.st)) return bail(rc);
+    if (r != 0) {
+      hipError_t e = hipMemcpyPeerAsync(gathered + po.off[r], root->device, dst, s->device,
+                                        n * sizeof(float), s->stream);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&me.arrived, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(me.arrived, s->stream);
+      if (e != hipSuccess) return bail(fail(RTR_ERR_DEVICE, std::string("gather: ") + hipGetErrorString(e)));
+    }
+  };
+  {
+    std::vector<std::thread> threads;
+    for (int r = 1; r < R; r++) threads.emplace_back(work, r);
+    work(0);
+    for (auto &t : threads) t.join();
+  }
+  auto t_joined = std::chrono::steady_clock::now();
+  int rc = RTR_OK;
+  {
+    DeviceGuard guard(root->device);
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < R; r++) {
+      if (ranks[r].rc != RTR_OK && rc == RTR_OK) rc = fail(ranks[r].rc, "partition " + std::to_string(r) + ": " + ranks[r].error);
+      if (ranks[r].arrived && e == hipSuccess) e = hipStreamWaitEvent(root->stream, ranks[r].arrived, 0);
+    }
+    if (rc == RTR_OK && e == hipSuccess) {
+      const size_t n_pix = (size_t)W * H;
+      hipLaunchKernelGGL(k_unpartition, dim3(blocks_for(n_pix)), dim3(kBlock), 0, root->stream, W, H, R,
+                         base.tile_cols, po, (const float *)gathered, image);
+      e = hipGetLastError();
+      if (e == hipSuccess && h_rgb)
+        e = hipMemcpyAsync(h_rgb, image, total * sizeof(float), hipMemcpyDeviceToHost, root->stream);
+    }
+    // also on failure: no copy may still be in flight when the events go away
+    hipError_t e2 = hipStreamSynchronize(root->stream);
+    for (int r = 1; r < R; r++) {
+      DeviceGuard g2(scenes[r]->device);
+      (void)hipStreamSynchronize(scenes[r]->stream);
+    }
+    for (Rank &k : ranks)
+      if (k.arrived) (void)hipEventDestroy(k.arrived);
+    if (rc == RTR_OK && (e != hipSuccess || e2 != hipSuccess))
+      rc = fail(RTR_ERR_DEVICE, std::string("gather: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
+  if (rc) return rc;
+  if (stats) {
+    auto t_end = std::chrono::steady_clock::now();
+    const rtr_stats &s0 = ranks[0].st;
+    stats->chunk_spp = s0.chunk_spp;
+    stats->pool_size = s0.pool_size;
+    stats->mode = s0.mode;
+    stats->n_columns = W;
+    stats->n_devices = R;
+    for (const Rank &k : ranks) {
+      stats->samples += k.st.samples;
+      stats->rays += k.st.rays;
+      stats->vertices += k.st.vertices;
+      stats->trace_launches += k.st.trace_launches;
+      stats->fused_launches += k.st.fused_launches;
+      stats->iterations = std::max(stats->iterations, k.st.iterations);
+      // kernel times: the slowest partition's, which is what the image waited for
+      stats->ms_trace = std::max(stats->ms_trace, k.st.ms_trace);
+      stats->ms_logic = std::max(stats->ms_logic, k.st.ms_logic);
+      stats->ms_other = std::max(stats->ms_other, k.st.ms_other);
+      stats->ms_fused = std::max(stats->ms_fused, k.st.ms_fused);
+    }
+    stats->ms_gather = std::chrono::duration<double, std::milli>(t_end - t_joined).count();
+    stats->ms_total = std::chrono::duration<double, std::milli>(t_end - t_start).count();
+  }
+  return RTR_OK;
+}
+
+int rtr_render_pt_multi(rtr_scene *const *scenes, int32_t n_scenes, const rtr_camera *cam,
+                        const rtr_render_params *prm, float *rgb_out, rtr_stats *stats) {
+  return render_multi(scenes, n_scenes, cam, prm, nullptr, rgb_out, stats);
+}
+
+int rtr_render_pt_multi_device(rtr_scene *const *scenes, int32_t n_scenes, const rtr_camera *cam,
+                               const rtr_render_params *prm, float *d_rgb_out, rtr_stats *stats) {
+  return render_multi(scenes, n_scenes, cam, prm, d_rgb_out, nullptr, stats);
 }
 
 } /* extern "C" */

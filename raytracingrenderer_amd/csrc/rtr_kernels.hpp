@@ -97,15 +97,51 @@ struct RenderArgs {
 RTR_DEV unsigned lane_id() { return threadIdx.x & 63u; }
 RTR_DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
 
+// Which columns of the image a render covers: the image is cut into tiles of tile_cols
+// columns and partition part_index of part_count takes the tiles t with
+// t % part_count == part_index, packed in increasing column order.
+struct ColumnMap {
+  int32_t part_index, part_count, tile_cols;
+  // local column -> image column (only the last tile of the image can be narrower than
+  // tile_cols, so every tile before a given local column is full)
+  RTR_DEV int column(int lc) const {
+    if (part_count <= 1) return lc;
+    return ((lc / tile_cols) * part_count + part_index) * tile_cols + lc % tile_cols;
+  }
+};
+
 // ---- ray generation: src/Render.cpp:654 ----
 __global__ void __launch_bounds__(kBlock)
-k_raygen(RenderArgs a, CameraSetup cam, const int32_t *__restrict__ cols, float4 *__restrict__ dir) {
+k_raygen(RenderArgs a, CameraSetup cam, ColumnMap cm, float4 *__restrict__ dir) {
   int lp = blockIdx.x * kBlock + threadIdx.x;
   if (lp >= a.n_pix) return;
   int lc = lp / a.H, j = lp - lc * a.H;
-  int i = cols[lc];
+  int i = cm.column(lc);
   V3 d = unit(cam.front + (float)(-a.W / 2 + i) * cam.hstep + (float)(-a.H / 2 + j) * cam.vstep);
   dir[lp] = pack(d, (uint32_t)(i * a.H + j));
+}
+
+// ---- the framebuffers of all partitions, one after the other -> the whole image ----
+// Partition r's columns (n_cols of them, column-major, 3 floats per pixel) start at
+// float offset part_off[r] of `parts`; the image has the reference's layout (i*H + j).
+constexpr int kMaxParts = 64;
+struct PartOffsets {
+  unsigned long long off[kMaxParts];
+};
+__global__ void __launch_bounds__(kBlock)
+k_unpartition(int W, int H, int part_count, int tile_cols, PartOffsets po,
+              const float *__restrict__ parts, float *__restrict__ image) {
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;  // pixel i*H + j
+  if (idx >= (size_t)W * H) return;
+  const int i = (int)(idx / H), j = (int)(idx - (size_t)i * H);
+  const int tile = i / tile_cols;
+  const int r = tile % part_count;
+  const int lc = (tile / part_count) * tile_cols + i % tile_cols;
+  const float *src = parts + po.off[r] + 3 * ((size_t)lc * H + j);
+  float *dst = image + 3 * idx;
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
 }
 
 // ---- traversal over explicit ray arrays (the rtr_trace_closest entry point) ----

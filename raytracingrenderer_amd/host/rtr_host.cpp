@@ -219,6 +219,7 @@ Scene::Scene(Camera *_camera) : camera(_camera), bvh(new BVH()) {}
 
 Scene::~Scene() {
   if (device) rtr_scene_destroy(device);
+  dropReplicas();
   delete bvh;
 }
 
@@ -458,7 +459,29 @@ const FlatScene &Scene::flatten() {
     rtr_scene_destroy(device);
     device = nullptr;
   }
+  dropReplicas();
   return flat;
+}
+
+void Scene::dropReplicas() {
+  for (rtr_scene *r : replicas) rtr_scene_destroy(r);
+  replicas.clear();
+  replicaDevices.clear();
+}
+
+const std::vector<rtr_scene *> &Scene::deviceScenes(const std::vector<int> &devices) {
+  flatten();
+  if (devices != replicaDevices) {
+    dropReplicas();
+    rtr_scene_desc d = flat.desc();
+    for (int dev : devices) {
+      rtr_scene *r = nullptr;
+      rtr_check(rtr_scene_create(&d, dev, &r), "rtr_scene_create");
+      replicas.push_back(r);
+      replicaDevices.push_back(dev);
+    }
+  }
+  return replicas;
 }
 
 rtr_scene *Scene::deviceScene() {
@@ -554,15 +577,30 @@ void Render::renderPathTracing(Scene &scene, const unsigned int &imageWidth,
   p.profile = options.profile ? 1 : 0;
   p.mode = options.mode;
   p.streams = options.streams;
-  int32_t n_cols = 0;
-  rtr_check(rtr_partition_columns(p.width, p.part_index, p.part_count, p.tile_cols, &n_cols, nullptr),
-            "rtr_partition_columns");
-  delete buffer;
-  buffer = new std::vector<Vector3f>((size_t)n_cols * imageHeight);
   static_assert(sizeof(Vector3f) == 3 * sizeof(float), "Vector3f must be three packed floats");
-  rtr_check(rtr_render_pt(scene.deviceScene(), &cam, &p, reinterpret_cast<float *>(buffer->data()),
-                          &lastStats),
-            "rtr_render_pt");
+  int32_t n_cols = 0;
+  if (!options.devices.empty()) {
+    // several GPUs: the library partitions, renders concurrently and gathers
+    if (options.part_count > 1)
+      throw std::invalid_argument("RenderOptions: devices and part_count are exclusive");
+    n_cols = p.width;
+    p.part_index = 0;
+    p.part_count = 0;
+    const std::vector<rtr_scene *> &scenes = scene.deviceScenes(options.devices);
+    delete buffer;
+    buffer = new std::vector<Vector3f>((size_t)n_cols * imageHeight);
+    rtr_check(rtr_render_pt_multi(scenes.data(), (int32_t)scenes.size(), &cam, &p,
+                                  reinterpret_cast<float *>(buffer->data()), &lastStats),
+              "rtr_render_pt_multi");
+  } else {
+    rtr_check(rtr_partition_columns(p.width, p.part_index, p.part_count, p.tile_cols, &n_cols, nullptr),
+              "rtr_partition_columns");
+    delete buffer;
+    buffer = new std::vector<Vector3f>((size_t)n_cols * imageHeight);
+    rtr_check(rtr_render_pt(scene.deviceScene(), &cam, &p, reinterpret_cast<float *>(buffer->data()),
+                            &lastStats),
+              "rtr_render_pt");
+  }
   if (!fileName.empty()) saveFile(*buffer, fileName, imageHeight, (unsigned)n_cols);
   std::cout << "render end, spp = " << spp << "\n";
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count();
@@ -601,6 +639,7 @@ struct HostScene {
   std::vector<Material *> mats;
   std::vector<Object *> objs;
   Render render;
+  rtr_scene_desc desc{};
   std::string error;
   ~HostScene() {
     delete scene;
@@ -743,6 +782,17 @@ rtr_scene *rtrh_device_scene(void *hs) {
   return s;
 }
 
+// the flattened scene as the C ABI takes it (valid until the scene changes); NULL on failure
+const rtr_scene_desc *rtrh_scene_desc(void *hs) {
+  HostScene *h = (HostScene *)hs;
+  const rtr_scene_desc *out = nullptr;
+  guarded([&] {
+    h->desc = h->scene->flatten().desc();
+    out = &h->desc;
+  });
+  return out;
+}
+
 int rtrh_material_id(void *hs, int material) {
   // id of the host material in the flattened table (-1 if no primitive uses it)
   HostScene *h = (HostScene *)hs;
@@ -801,6 +851,12 @@ int64_t rtrh_create_photon_map(void *hs, uint32_t seed, uint32_t n, float *pos, 
   return rc ? -1 : filled;
 }
 
+// RenderOptions::devices for the next rtrh_render calls (n = 0: back to the scene's own device)
+int rtrh_set_render_devices(void *hs, const int *devices, int n) {
+  HostScene *h = (HostScene *)hs;
+  return guarded([&] { h->render.options.devices.assign(devices, devices + (n > 0 ? n : 0)); });
+}
+
 // Render::renderPathTracing; file may be NULL/"" (no PPM).  rgb gets the buffer.
 int rtrh_render(void *hs, unsigned W, unsigned H, unsigned spp, const char *file,
                 const rtr_render_params *opt, float *rgb, rtr_stats *stats) {
@@ -819,6 +875,7 @@ int rtrh_render(void *hs, unsigned W, unsigned H, unsigned spp, const char *file
       h->render.options.mode = opt->mode;
       h->render.options.streams = opt->streams;
     }
+    if (!h->render.options.devices.empty()) h->render.options.part_count = 1;
     h->render.renderPathTracing(*h->scene, W, H, spp, file ? std::string(file) : std::string());
     const std::vector<Vector3f> &b = h->render.getBuffer();
     if (rgb) memcpy(rgb, b.data(), b.size() * sizeof(Vector3f));

@@ -216,9 +216,12 @@ class Scene {
   std::vector<Object *> lights;
   BVH *bvh;
   rtr_scene *device = nullptr;
+  std::vector<rtr_scene *> replicas;  // deviceScenes(): one upload per entry of its list
+  std::vector<int> replicaDevices;
   FlatScene flat;
   int deviceIndex = 0;
   bool flatValid = false;
+  void dropReplicas();
 
  public:
   explicit Scene(Camera *_camera);
@@ -244,6 +247,9 @@ class Scene {
   bool setNodeBound(int flatIndex, const Bound3 &b);
   const FlatScene &flatten();  // (re)built after rebuildBVH
   rtr_scene *deviceScene();    // uploaded on first use; throws if no device
+  // The scene on each device of the list (uploaded on first use, kept until the list or the
+  // scene changes).  A device may appear more than once: every entry is a replica of its own.
+  const std::vector<rtr_scene *> &deviceScenes(const std::vector<int> &devices);
   const std::vector<Object *> &getLights() const { return lights; }
 };
 
@@ -255,9 +261,14 @@ struct RenderOptions {  // what the reference hard-codes, see rtr_render_params
   int max_depth = 0;
   float rr_prob = 0;
   int chunk_spp = 0, pool_size = 0;
-  int part_index = 0, part_count = 1, tile_cols = 8;
+  int part_index = 0, part_count = 1, tile_cols = 0;  // tile_cols 0: 8, or balanced tiles with `devices`
   bool profile = false;
   int mode = 0, streams = 0;  // rtr_render_params::mode / ::streams
+  // GPUs to render on, e.g. {0, 1, 2, 3, 4, 5, 6, 7}: the image is cut into interleaved column
+  // tiles, one partition per entry, rendered concurrently and gathered on the first device
+  // (rtr_render_pt_multi).  Empty: the scene's own device (Scene::setDevice).  part_index /
+  // part_count must be left alone when this is set.
+  std::vector<int> devices;
 };
 
 // ---- include/Photon.h ----

@@ -276,13 +276,15 @@ def test_gpu_photon_map(gsc):
 
 
 @pytest.mark.gpu
-def test_gpu_converged_image_matches_reference(gsc):
+@pytest.mark.parametrize("size", [128, 256])
+def test_gpu_converged_image_matches_reference(gsc, size):
     """>=4096 spp image tier: linear float buffers, RMSE <= 1.5 x the RMSE between two
     independent reference renders at the same spp, mean luminance within 0.5 %."""
     rt, sg = gsc
-    ref = _load("ref_render_128x128_4096spp.npy")
-    noise = float(_load("ref_render_128x128_4096spp_noise.npy"))
-    rgb, st = sg.render(128, 128, 4096, seed=1)
+    ref = _load("ref_render_%dx%d_4096spp.npy" % (size, size))
+    noise = float(_load("ref_render_%dx%d_4096spp_noise.npy" % (size, size)))
+    assert np.isfinite(ref).all() and noise > 0
+    rgb, st = sg.render(size, size, 4096, seed=1)
     lum = lambda a: (a * np.array([0.2126, 0.7152, 0.0722], f32)).sum(1)
     rel = abs(lum(rgb).mean() - lum(ref).mean()) / lum(ref).mean()
     rmse = float(np.sqrt(((rgb - ref) ** 2).mean()))

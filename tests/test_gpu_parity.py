@@ -559,3 +559,89 @@ def test_host_api_render_and_ppm(rt, scenes, tmp_path):
     body = np.frombuffer(data[len(header):], np.uint8).reshape(-1, 3)
     want = np.array([[O.lib.orc_tonemap(float(v)) for v in px] for px in rgb], np.uint8)
     assert np.array_equal(body, want)
+
+
+# ---------------- several devices behind one call (rtr_render_pt_multi) ----------------
+def test_multi_device_render_equals_single_device(rt, scenes):
+    """Virtual ranks: three uploads of the scene on device 0 render three partitions on three
+    host threads and streams, the partitions travel to the first one's buffer by peer copy
+    and one kernel restores column order.  The image must be the one-device image bit for
+    bit, in host memory and in device memory, and through the C++ mirror's device list."""
+    import torch
+    O, so, sg = scenes
+    W, H, spp = 100, 36, 6
+    full, st = sg.render(W, H, spp, seed=9, chunk_spp=2)
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 5):
+        got, sm = sg.render_multi(W, H, spp, devs, seed=9, chunk_spp=2)
+        _assert_images_equal(got, full)
+        assert sm.n_devices == len(devs) and sm.n_columns == W
+        assert (sm.samples, sm.rays, sm.vertices) == (st.samples, st.rays, st.vertices)
+    # explicit tiles, one of them narrow, more partitions than tiles
+    got, sm = sg.render_multi(W, H, spp, [0] * 4, seed=9, chunk_spp=2, tile_cols=48)
+    _assert_images_equal(got, full)
+    # the wavefront loop under the same call
+    got, sm = sg.render_multi(W, H, spp, [0, 0], seed=9, chunk_spp=2, mode=rt.MODE_WAVEFRONT)
+    _assert_images_equal(got, full)
+    assert sm.mode == rt.MODE_WAVEFRONT
+    # device output
+    out = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+    sg.render_multi(W, H, spp, [0, 0, 0], d_ptr=out.data_ptr(), seed=9, chunk_spp=2)
+    torch.cuda.synchronize()
+    _assert_images_equal(out.cpu().numpy().reshape(-1, 3), full)
+    # Render::renderPathTracing with RenderOptions::devices
+    got, sh = sg.render_via_host_api(W, H, spp, devices=[0, 0, 0], seed=9, chunk_spp=2)
+    _assert_images_equal(got, full)
+    assert sh.n_devices == 3
+    got, sh = sg.render_via_host_api(W, H, spp, seed=9, chunk_spp=2)  # and back to one device
+    _assert_images_equal(got, full)
+    assert sh.n_devices == 1
+
+
+def test_multi_device_argument_errors(rt, scenes):
+    import ctypes as C
+    O, so, sg = scenes
+    with pytest.raises(rt.RtrError, match="part_count"):
+        sg.render_multi(16, 16, 2, [0, 0], part_count=2)
+    with pytest.raises(rt.RtrError):
+        sg.render_multi(16, 16, 2, [rt.device_count() + 3])
+    from raytracingrenderer_amd import api
+    h = sg.device_scenes([0])[0]
+    arr = (C.c_void_p * 2)(h.value, h.value)
+    p = sg.make_params(16, 16, 2)
+    p.part_count = 0
+    cam = sg.camera_struct()
+    out = np.zeros((256, 3), f32)
+    rc = api.hip_lib().rtr_render_pt_multi(arr, 2, C.byref(cam), C.byref(p),
+                                           out.ctypes.data_as(C.POINTER(C.c_float)), None)
+    assert rc == -1 and b"twice" in api.hip_lib().rtr_last_error()
+
+
+def test_render_2048_square_image(rt, scenes):
+    """2048 x 2048 (4.2 M pixels, the multi-GPU configuration's image): the fused kernel at
+    the full 4096 spp (1.7e10 samples), its 8-partition reassembly through the multi-device
+    call at 512 spp, and the wavefront loop at 64 spp must agree bit for bit wherever they
+    render the same thing; default chunking keeps the partial sums at 2 GiB."""
+    O, so, sg = scenes
+    W = H = 2048
+    lumw = np.array([0.2126, 0.7152, 0.0722], f32)
+    a, sa = sg.render(W, H, 64, seed=2)
+    assert sa.mode == rt.MODE_FUSED and sa.samples == W * H * 64
+    assert W * H * ((64 + sa.chunk_spp - 1) // sa.chunk_spp) <= 1 << 27
+    b, sb = sg.render(W, H, 64, seed=2, mode=rt.MODE_WAVEFRONT, chunk_spp=sa.chunk_spp)
+    _assert_images_equal(b, a)
+    assert (sb.rays, sb.vertices) == (sa.rays, sa.vertices)
+    del b
+    c, sc = sg.render_multi(W, H, 64, [0] * 8, seed=2, chunk_spp=sa.chunk_spp)
+    _assert_images_equal(c, a)
+    assert sc.rays == sa.rays
+    del c
+    full, st = sg.render(W, H, 4096, seed=0)
+    assert st.samples == W * H * 4096 and st.chunk_spp == 128
+    assert 3.0 < st.rays / st.samples < 3.5
+    lum = (full * lumw).sum(1)
+    assert np.isfinite(full).all() and 0.15 < lum.mean() < 0.18
+    # the light's pixels are exact: emission, summed and divided (src/Render.cpp:85-87)
+    centre = full.reshape(W, H, 3)[W // 2, H // 2]
+    assert np.allclose(centre, [47.834801, 38.566399, 31.080799], rtol=1e-6)
+    # 4096 spp against 64 spp of another seed: same picture, less noise
+    assert abs(lum.mean() - (a * lumw).sum(1).mean()) / lum.mean() < 0.01
