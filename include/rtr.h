@@ -283,6 +283,26 @@ int rtr_render_pt_device(rtr_scene *scene, const rtr_camera *camera,
                          const rtr_render_params *params, float *d_rgb_out, rtr_stats *stats);
 
 /*
+ * rtr_render_pt_device for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments, same image bit for bit (for the
+ * same chunk_spp), and it calls no hipMalloc, hipFree or other allocating routine:
+ * its device workspace (per-pixel records, the pixel list, partial sums, counters)
+ * is a fixed 37 MiB array inside the library, of which every GPU the library runs
+ * on holds one copy until the process ends.  Limits, rejected with RTR_ERR_INVALID
+ * or RTR_ERR_UNSUPPORTED and a message: at most 2^18 pixels per call (512 x 512, or
+ * one partition of a larger image), pixels x partial sums per pixel at most 2^20
+ * (the default chunk_spp is chosen to fit), the fused kernel only (mode 0 or 2 on a
+ * scene of at most 2^19 nodes), profile = 0.  stats gets what the host knows
+ * (samples, chunk_spp, n_columns, mode, ms_total); ray and vertex counts stay 0.
+ * All calls on one GPU share the array, whatever scene they use: calls that
+ * overlap on one GPU race.  Synchronises the scene's stream before returning.
+ */
+int rtr_render_pt_device_noalloc(rtr_scene *scene, const rtr_camera *camera,
+                                 const rtr_render_params *params, float *d_rgb_out,
+                                 rtr_stats *stats);
+
+/*
  * Render::renderPathTracing on several GPUs at once: the reference fans the image
  * out to 16 threads, one band of rows each, and joins them (src/Render.cpp:667-684).
  * Here scenes[r] (the same scene uploaded to n_scenes devices with rtr_scene_create;

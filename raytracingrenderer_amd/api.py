@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "rtr_trace_closest", "rtr_trace_closest_device", "rtr_material_eval", "rtr_material_sample",
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
-    "rtr_create_photon_map_device", "rtr_render_pt_multi",
+    "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
     "rtr_render_pt_multi_device",
 ]
 
@@ -97,6 +97,7 @@ def hip_lib():
                                     C.POINTER(Stats)]
         L.rtr_render_pt_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams),
                                            C.c_void_p, C.POINTER(Stats)]
+        L.rtr_render_pt_device_noalloc.argtypes = L.rtr_render_pt_device.argtypes
         L.rtr_render_pt_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera),
                                           C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
         L.rtr_render_pt_multi_device.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera),
@@ -461,6 +462,16 @@ class HostScene:
         _check(hip_lib().rtr_render_pt_multi(arr, len(scenes), C.byref(cam), C.byref(p), _f(rgb),
                                              C.byref(st)), "rtr_render_pt_multi")
         return rgb, st
+
+    def render_device_noalloc(self, W, H, spp, d_ptr, **kw):
+        """rtr_render_pt_device_noalloc into a device buffer (address as int)."""
+        p = self.make_params(W, H, spp, **kw)
+        st = Stats()
+        cam = self.camera_struct()
+        _check(hip_lib().rtr_render_pt_device_noalloc(self.device_scene(), C.byref(cam), C.byref(p),
+                                                      C.c_void_p(d_ptr), C.byref(st)),
+               "rtr_render_pt_device_noalloc")
+        return st
 
     def render_via_host_api(self, W, H, spp, file=None, devices=None, **kw):
         """Render::renderPathTracing of the host library (optionally writes file.ppm);

@@ -96,6 +96,7 @@ struct rtr_scene {
   int n_materials = 0;
   bool lds_geometry = false;  // scene small enough for the kernels to stage it in LDS
   int fused_grid = 0;         // resident workgroups of the fused sampling kernel (0: not queried yet)
+  unsigned char *noalloc_scratch = nullptr;  // this device's copy of the scratch array
   int stream_grid = 0;        // the same for k_trace_api_stream
   int queue_grid = 0;         // and for k_trace_queue_stream
   int connect_grid = 0;       // and for k_check_connectable_stream
@@ -428,11 +429,56 @@ int enqueue_resolve(const RenderPlan &pl, const RenderBuffers &b, float *d_rgb, 
   return RTR_OK;
 }
 
+// ---- device memory of the entry point that allocates nothing ----
+// Largest render it takes, and how its scratch array is cut up (every part 256-byte
+// aligned): counters, five per-pixel float4 arrays, the pixel list, the partial sums.
+constexpr size_t kNoAllocMaxPixels = (size_t)1 << 18;  // e.g. 512 x 512
+constexpr size_t kNoAllocMaxUnits = (size_t)1 << 20;   // pixels x partial sums per pixel
+constexpr size_t kNoAllocCounters = 256;
+constexpr size_t kNoAllocBytes = kNoAllocCounters + 5 * 16 * kNoAllocMaxPixels + 4 * kNoAllocMaxPixels +
+                                 16 * kNoAllocMaxUnits;
+static_assert(sizeof(Counters) <= kNoAllocCounters, "counters outgrew their part of the scratch array");
+
 }  // namespace
+
+// Host code must never use this name as an address: every device holds its own copy, and
+// its address there comes from hipGetSymbolAddress (noalloc_scratch()).
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNoAllocBytes];
 
 namespace {
 
 constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+
+// The scratch array's address on `device`, which must be the current device.  Resolved
+// once per device (scene creation does it, so that a render has nothing left to set up).
+int noalloc_scratch(int device, unsigned char **out) {
+  if (device < 0 || device >= kMaxDevices) return fail(RTR_ERR_UNSUPPORTED, "device index beyond 63");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));
+    if (!p) return fail(RTR_ERR_DEVICE, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = (unsigned char *)p;
+  }
+  *out = g_scratch_ptr[device];
+  return RTR_OK;
+}
+
+RenderBuffers scratch_buffers(unsigned char *base) {
+  RenderBuffers b;
+  unsigned char *p = base;
+  b.cnt = (Counters *)p; p += kNoAllocCounters;
+  float4 *px[5];
+  for (auto &q : px) { q = (float4 *)p; p += 16 * kNoAllocMaxPixels; }
+  b.pix_dir = px[0]; b.pix_hit = px[1];
+  b.pc = PixelCache{px[2], px[3], px[4]};
+  b.shade_list = (uint32_t *)p; p += 4 * kNoAllocMaxPixels;
+  b.partial = (float4 *)p;
+  return b;
+}
+
 // pairs of devices whose peer access has been switched on (or found impossible)
 std::mutex g_peer_mutex;
 bool g_peer_tried[kMaxDevices][kMaxDevices] = {};
@@ -781,6 +827,10 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->dl.tri_area = s->tri_area.ptr;
   s->dl.n_lights = d->n_lights;
   s->dl.total_area = total_area;
+  // set up now what rtr_render_pt_device_noalloc must not do later: this device's address
+  // of the scratch array and the fused kernel's launch shape
+  if ((rc = noalloc_scratch(device, &s->noalloc_scratch))) return bail(rc);
+  if ((rc = fused_grid(s))) return bail(rc);
   *out = s;
   return RTR_OK;
 }
@@ -1286,6 +1336,51 @@ int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *
   if (stats)
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return RTR_OK;
+}
+
+int rtr_render_pt_device_noalloc(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *prm,
+                                 float *d_rgb, rtr_stats *stats) {
+  if (!s || !cam || !prm || !d_rgb) return fail(RTR_ERR_INVALID, "null argument");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  auto t_start = std::chrono::steady_clock::now();
+  if (prm->profile) return fail(RTR_ERR_UNSUPPORTED, "profile=1 creates events: not in the call that allocates nothing");
+  RenderPlan pl;
+  if (int rc = plan_render(s, cam, prm, kNoAllocMaxUnits, pl)) return rc;
+  if (!pl.fused)
+    return fail(RTR_ERR_UNSUPPORTED, "the wavefront loop needs a path pool: only the fused kernel runs without allocating");
+  if ((size_t)pl.a.n_pix > kNoAllocMaxPixels)
+    return fail(RTR_ERR_INVALID, "more than 262144 pixels (2^18) in one call: beyond the fixed scratch array");
+  if (pl.units > kNoAllocMaxUnits)
+    return fail(RTR_ERR_INVALID, "pixels x partial sums per pixel beyond 1048576 (2^20): raise chunk_spp");
+  if (pl.a.n_pix == 0) return RTR_OK;
+  if (!s->noalloc_scratch || s->fused_grid == 0)
+    return fail(RTR_ERR_DEVICE, "scene was created without the scratch array's address");
+  DeviceGuard guard(s->device);
+  hipStream_t st = s->stream;
+  // Every call on this GPU shares the one array: the counters must start at zero (the front
+  // end clears them); every partial sum and per-pixel record this render reads is written
+  // by it first, so what an earlier, larger render left behind is never looked at.
+  const RenderBuffers rb = scratch_buffers(s->noalloc_scratch);
+  EventSpans ev;  // off: records nothing, creates nothing
+  if (int rc = enqueue_front(s, pl, rb, st, ev)) return rc;
+  if (int rc = enqueue_fused(s, pl, rb, st, ev)) return rc;
+  if (int rc = enqueue_resolve(pl, rb, d_rgb, st, ev)) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (stats) {
+    // what the host knows; ray and vertex counts stay on the device (reading them back
+    // would need a staging buffer)
+    stats->samples = (uint64_t)pl.a.n_pix * pl.a.spp;
+    stats->iterations = 1;
+    stats->chunk_spp = pl.a.chunk_spp;
+    stats->mode = RTR_MODE_FUSED;
+    stats->n_columns = pl.a.n_cols;
+    stats->fused_launches = 1;
+    stats->trace_launches = 1;
+    stats->n_devices = 1;
+    stats->ms_total =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  }
   return RTR_OK;
 }
 
