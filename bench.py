@@ -71,8 +71,8 @@ def cpu_baseline(W, H):
         finally:
             os.dup2(saved, 1)
             os.close(saved)
-        return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": 16,
-                "kind": "reference",
+        return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": min(16, cores),
+                "threads": 16, "kind": "reference",
                 "sample": "%dx%d at %d spp, Render::renderPathTracing with its 16 std::threads "
                           "(includes its PPM write), %.1f s; host exposes %d cpus (%s)"
                           % (W, H, spp, dt, cores, model)}
@@ -87,6 +87,99 @@ def cpu_baseline(W, H):
             "kind": "port", "sample": "%dx%d at %d spp, %.1f s (%s)" % (W, H, spp, dt, model)}
 
 
+def timed_render(torch, scene, W, H, spp, dev, **kw):
+    """One render into a device buffer, after a short one that sizes the workspace."""
+    buf = torch.empty(W * H * 3, dtype=torch.float32, device=dev)
+    scene.render_device(W, H, max(1, spp // 64), buf.data_ptr(), **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = scene.render_device(W, H, spp, buf.data_ptr(), profile=True, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"msamples_per_s": W * H * spp / dt / 1e6, "ms": dt * 1e3, "mrays_per_s_unique": st.rays / dt / 1e6,
+            "vertices_per_sample": st.vertices / st.samples, "rays_per_sample": st.rays / st.samples,
+            "mode": "fused" if st.mode == 2 else "wavefront", "chunk_spp": st.chunk_spp,
+            "kernel_ms": {"fused": st.ms_fused, "trace": st.ms_trace, "logic": st.ms_logic,
+                          "other": st.ms_other},
+            "iterations": st.iterations}
+
+
+def extras(torch, rt, dev, seed):
+    """The other measurement inputs on one GPU, a few seconds each: the 2048 x 2048 image at
+    4096 spp, the specular / microfacet variant with max_depth 16 and continue probability
+    0.95, and the default scene plus a 1 M-triangle height field (closest-hit throughput
+    against the bytes its traversal reads, then a render)."""
+    from raytracingrenderer_amd import scenes
+    out = []
+    sg = rt.default_scene()
+    r = timed_render(torch, sg, 2048, 2048, 4096, dev, seed=seed)
+    r["workload"] = "default Cornell box, 2048x2048 at 4096 spp, one GPU"
+    out.append(r)
+    sg.close()
+
+    sv = rt.HostScene.from_spec(scenes.variant_scene_spec())
+    r = timed_render(torch, sv, 784, 784, 1024, dev, seed=seed, max_depth=16, rr_prob=0.95)
+    r["workload"] = ("Cornell box with specular / microfacet spheres, max_depth 16, continue "
+                     "probability 0.95 (both knobs are extensions: the reference hard-codes 0.6 "
+                     "and has no depth cap), 784x784 at 1024 spp")
+    out.append(r)
+    sv.close()
+
+    n = 708
+    t0 = time.perf_counter()
+    spec = scenes.heightfield_spec(n)
+    t1 = time.perf_counter()
+    sm = rt.HostScene.from_spec(spec)  # Scene::rebuildBVH of the host mirror: trees
+    t2 = time.perf_counter()
+    sm.device_scene()                  # flatten + rtr_scene_create
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    nr = 1 << 24
+    org, d = scenes.interior_rays(nr, seed=5)
+    o_t, d_t = torch.from_numpy(org).to(dev), torch.from_numpy(d).to(dev)
+    prim = torch.empty(nr, dtype=torch.int32, device=dev)
+    t = torch.empty(nr, dtype=torch.float32, device=dev)
+    boxes, tris, sphs = sm.count_work(o_t.data_ptr(), d_t.data_ptr(), nr)
+    bytes_per_launch = 32.0 * boxes + 48.0 * tris + 16.0 * sphs + 36.0 * nr
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    stream = torch.cuda.current_stream(dev)
+    sm.intersect_device(o_t.data_ptr(), d_t.data_ptr(), nr, prim.data_ptr(), t.data_ptr(),
+                        stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    reps = 3
+    ev[0].record(stream)
+    for _ in range(reps):
+        sm.intersect_device(o_t.data_ptr(), d_t.data_ptr(), nr, prim.data_ptr(), t.data_ptr(),
+                            stream=stream.cuda_stream)
+    ev[1].record(stream)
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+    rec = {"workload": "default scene + %dx%d jittered height field (%d triangles, 2 M tree nodes)"
+                       % (n, n, 2 * n * n),
+           "scene_ms": {"mesh_arrays": (t1 - t0) * 1e3, "host_trees": (t2 - t1) * 1e3,
+                        "flatten_and_scene_create": (t3 - t2) * 1e3},
+           "trace": {"rays": nr, "mrays_per_s": nr / (ms * 1e-3) / 1e6, "ms_per_launch": ms,
+                     "boxes_per_ray": boxes / nr, "triangles_per_ray": tris / nr,
+                     "spheres_per_ray": sphs / nr,
+                     "roofline": {"kernel": "k_trace_api_stream", "bound": "hbm",
+                                  "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                  "bytes_per_ray": bytes_per_launch / nr,
+                                  "note": "algorithmic bytes (32 B per box the reference tests, 48 B per "
+                                          "triangle, 16 B per sphere, 36 B per ray in and out), counted "
+                                          "on the device for these rays; launches timed with events on the "
+                                          "launch stream.  The 110 MB scene fits the 256 MB Infinity "
+                                          "Cache, so the bytes are served by L2 / Infinity Cache / HBM "
+                                          "together: the bound is the memory fabric, priced at the HBM peak"}}}
+    del o_t, d_t, prim, t
+    r = timed_render(torch, sm, 784, 784, 64, dev, seed=seed)
+    rec["render_784x784_64spp"] = r
+    out.append(rec)
+    sm.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +190,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other measurement inputs reported after the headline line's timing")
     ap.add_argument("--pool", type=int, default=0, help="path pool size (0 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="samples per partial sum (0 = default)")
     ap.add_argument("--mode", type=int, default=0,
@@ -160,6 +255,7 @@ def main():
             agg["iterations"] += st.iterations
             agg["samples"] += st.samples
             agg["mode"] = st.mode
+            agg["chunk_spp"] = st.chunk_spp
         return st
 
     def fence():
@@ -196,6 +292,7 @@ def main():
         # Wavefront mode: k_trace_queue, one launch per bounce (the primary-ray launch
         # of each step is in the average too, with its own ray count).
         fused = agg["mode"] == 2
+        chunk_used = agg.get("chunk_spp", 0) or 1
         if fused:
             kernel = "k_render_fused"
             launches = max(agg["fused_launches"], 1)
@@ -210,7 +307,6 @@ def main():
             flop_per_launch = FLOP_PER_QUERY * queries
         rays_per_launch = queries
         tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        gbs = BYTES_PER_QUERY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -218,6 +314,23 @@ def main():
                 traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roofline = {"kernel": kernel, "bound": "valu", "achieved": tflops,
+                    "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / PEAK_FP32_VECTOR_TFLOPS,
+                    "traffic": traffic,
+                    "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch,
+                    "flop_per_query": FLOP_PER_QUERY, "flop_per_vertex": FLOP_PER_VERTEX,
+                    "note": "fp32 VALU-issue bound (the 37-node scene sits in LDS and the "
+                            "scalar cache); parity forbids FMA contraction, so at most half "
+                            "of the FMA-counted peak is reachable"}
+        if fused:
+            # nothing streams through HBM in this kernel by design (path state, rays and hits
+            # stay in registers): what it should move is its partial sums and the pixel cache
+            roofline["algorithmic_hbm_bytes_per_launch"] = 16.0 * W * H * -(-spp // chunk_used) + 52.0 * W * H
+        else:
+            gbs = BYTES_PER_QUERY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": gbs / PEAK_HBM_GBS, "bytes_per_query": BYTES_PER_QUERY}
         out = {
             "metric": "Msamples/sec (paths/s), Cornell box path tracing",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -238,18 +351,27 @@ def main():
                                          "trace": agg["ms_trace"] / args.steps,
                                          "logic": agg["ms_logic"] / args.steps,
                                          "other": agg["ms_other"] / args.steps},
-            "roofline": {"kernel": kernel, "bound": "valu", "achieved": tflops,
-                         "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch,
-                         "flop_per_query": FLOP_PER_QUERY, "flop_per_vertex": FLOP_PER_VERTEX,
-                         "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": gbs / PEAK_HBM_GBS, "bytes_per_query": BYTES_PER_QUERY},
-                         "note": "fp32 VALU-issue bound (the 37-node scene sits in LDS and the "
-                                 "scalar cache); parity forbids FMA contraction, so at most half "
-                                 "of the FMA-counted peak is reachable"},
+            "roofline": roofline,
         }
+        if world == 1:
+            # the reference's wall ends with the framebuffer on the host: the same render
+            # through the host-output entry point (one D2H copy more)
+            try:
+                scene.render(W, H, max(1, spp // 64), seed=args.seed, pool_size=args.pool,
+                             chunk_spp=args.chunk, mode=args.mode, streams=args.streams)
+                t0 = time.perf_counter()
+                scene.render(W, H, spp, seed=args.seed, pool_size=args.pool, chunk_spp=args.chunk,
+                             mode=args.mode, streams=args.streams)
+                dt = time.perf_counter() - t0
+                out["value_with_framebuffer_on_host"] = {"value": W * H * spp / dt / 1e6,
+                                                         "unit": "Msamples/s", "ms": dt * 1e3}
+            except Exception as e:
+                out["value_with_framebuffer_on_host"] = {"value": None, "error": repr(e)}
+        if world == 1 and not args.no_extras:
+            try:
+                out["extra"] = extras(torch, rt, dev, args.seed)
+            except Exception as e:  # reports, never a reason to lose the line
+                out["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(W, H)

@@ -206,6 +206,19 @@ int rtr_trace_closest_device(rtr_scene *scene, const float *d_org_xyz, const flo
                              float *d_nrm_xyz, void *stream);
 
 /*
+ * The work the reference's traversal does for a batch of rays (DEVICE pointers, rows of
+ * x,y,z), counted, not timed: boxes = calls of Bound3::intersect (src/Bound3.cpp:3-22; one
+ * per node of the flattened tree that BVH::intersect, src/BVH.cpp:66-80, enters -- the
+ * reference tests a mesh's box once more, as the leaf of the top tree and again as the
+ * root of the mesh's tree), triangles / spheres = calls of Trangle::intersect /
+ * Sphere::intersect.  A measurement aid: throughput of
+ * rtr_trace_closest_device is priced against these counts (32 bytes per box, 48 per
+ * triangle, 16 per sphere).  The pending work of the scene's stream is waited for.
+ */
+int rtr_trace_count_work(rtr_scene *scene, const float *d_org_xyz, const float *d_dir_xyz, size_t n,
+                         uint64_t *boxes, uint64_t *triangles, uint64_t *spheres);
+
+/*
  * Scene::checkConnectable (include/Scene.h:49-56), the visibility test the
  * reference's bidirectional integrator builds on: the closest hit along
  * a -> b, connected[i] = 1 iff something is hit and |distance - |b - a|| < 1e-3

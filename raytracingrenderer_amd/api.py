@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 
+from .scenes import default_scene_spec  # noqa: F401  (part of this module's interface)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(_HERE, "librtr_hip.so")
 HOST_SO = os.path.join(_HERE, "librtr_host.so")
@@ -60,7 +62,7 @@ ABI_SYMBOLS = [
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
     "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
-    "rtr_render_pt_multi_device",
+    "rtr_render_pt_multi_device", "rtr_trace_count_work",
 ]
 
 _hip = None
@@ -83,6 +85,9 @@ def hip_lib():
         L.rtr_trace_closest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
+        L.rtr_trace_count_work.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
         L.rtr_check_connectable.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.rtr_create_photon_map.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _fp, _fp, _fp,
                                             C.POINTER(C.c_uint64), _up]
@@ -314,6 +319,22 @@ class HostScene:
                                            _f(t), _f(pos), _f(nrm)), "rtr_trace_closest")
         return prim, t, pos, nrm
 
+    def intersect_device(self, d_org, d_dir, n, d_prim, d_t, d_pos=None, d_nrm=None, stream=None):
+        """rtr_trace_closest_device: device addresses as ints; enqueues, does not wait."""
+        _check(hip_lib().rtr_trace_closest_device(self.device_scene(), C.c_void_p(d_org),
+                                                  C.c_void_p(d_dir), n, C.c_void_p(d_prim),
+                                                  C.c_void_p(d_t), C.c_void_p(d_pos),
+                                                  C.c_void_p(d_nrm), C.c_void_p(stream)),
+               "rtr_trace_closest_device")
+
+    def count_work(self, d_org, d_dir, n):
+        """rtr_trace_count_work: (boxes, triangles, spheres) the reference's traversal tests
+        for the n rays at these device addresses."""
+        out = [C.c_uint64(0) for _ in range(3)]
+        _check(hip_lib().rtr_trace_count_work(self.device_scene(), C.c_void_p(d_org), C.c_void_p(d_dir),
+                                              n, *[C.byref(o) for o in out]), "rtr_trace_count_work")
+        return tuple(o.value for o in out)
+
     def create_photon_map(self, n, seed=0, via_host_api=False):
         """Render::createPhotonMap: (pos, wi, power, emission paths used); each array k x 3
         with k = n, or 0 for a scene without lights.  via_host_api: through the C++ mirror
@@ -490,49 +511,6 @@ class HostScene:
         if rc != 0:
             self._herr("render")
         return rgb, st
-
-
-def default_scene_spec():
-    """The scene of the reference's src/main.cpp:7-84 as data (materials, objects, camera)."""
-    def v(*a):
-        return np.array(a, dtype=f32)
-    le = (f32(8.0) * v(f32(0.747) + f32(0.058), f32(0.747) + f32(0.258), f32(0.747))
-          + f32(15.6) * v(f32(0.740) + f32(0.287), f32(0.740) + f32(0.160), f32(0.740))
-          + f32(18.4) * v(f32(0.737) + f32(0.642), f32(0.737) + f32(0.159), f32(0.737)))
-    z = v(0, 0, 0)
-    d = 1e-5
-    mats = [
-        ("light", DIFFUSE, le, z, z, d, d),
-        ("white", DIFFUSE, z, v(.6, .6, .6), z, d, d),
-        ("red", DIFFUSE, z, v(.6, .01, .01), z, d, d),
-        ("green", DIFFUSE, z, v(.01, .6, .01), z, d, d),
-        ("blue", DIFFUSE, z, v(.01, .01, .6), z, d, d),
-        ("yellow", DIFFUSE, z, v(.6, .6, .01), z, d, d),
-        ("pink", DIFFUSE, z, v(.01, .6, .6), z, d, d),
-        ("cyan", DIFFUSE, z, v(.6, .01, .6), z, d, d),
-        ("spec", SPECULAR, z, v(1, 1, 1), z, d, d),
-        ("micro", MICROFACET, z, v(.6, .01, .01), v(.6, .01, .01), 0.0, 0.5),
-    ]
-    cube = np.array([[0, 0, -512], [512, 0, -512], [0, 512, -512], [512, 512, -512],
-                     [0, 0, 0], [512, 0, 0], [0, 512, 0], [512, 512, 0]], dtype=f32)
-    objs = [
-        ("sphere", "light", (256, 256, -256), 20),
-        ("mesh", "red", cube, [0, 1, 2, 3, 2, 1]),
-        ("mesh", "white", cube, [0, 4, 1, 5, 1, 4]),
-        ("mesh", "yellow", cube, [2, 3, 6, 7, 6, 3]),
-        ("mesh", "pink", cube, [0, 2, 4, 6, 4, 2]),
-        ("mesh", "cyan", cube, [1, 5, 3, 7, 3, 5]),
-        ("sphere", "red", (256, 512 - 64, -256), 32),
-        ("sphere", "blue", (64, 256, -256), 32),
-        ("sphere", "green", (512 - 64, 256, -256), 32),
-        ("sphere", "micro", (256, 64, -256), 32),
-        ("sphere", "spec", (64, 64, -512 + 64), 64),
-        ("sphere", "spec", (64, 512 - 64, -512 + 64), 64),
-        ("sphere", "spec", (512 - 64, 64, -512 + 64), 64),
-        ("sphere", "spec", (512 - 64, 512 - 64, -512 + 64), 64),
-    ]
-    cam = dict(pos=(256, 256, 512), front=(0, 0, -1), up=(0, 1, 0), fov=45.0)
-    return dict(materials=mats, objects=objs, camera=cam)
 
 
 def default_scene():

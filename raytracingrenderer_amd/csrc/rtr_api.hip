@@ -881,6 +881,29 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
   return RTR_OK;
 }
 
+int rtr_trace_count_work(rtr_scene *s, const float *d_org, const float *d_dir, size_t n,
+                         uint64_t *boxes, uint64_t *triangles, uint64_t *spheres) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (boxes) *boxes = 0;
+  if (triangles) *triangles = 0;
+  if (spheres) *spheres = 0;
+  if (n == 0) return RTR_OK;
+  if (!d_org || !d_dir) return fail(RTR_ERR_INVALID, "null ray array");
+  DeviceGuard guard(s->device);
+  HIP_TRY(s->ph_sums.reserve(3));  // three 64-bit sums
+  HIP_TRY(hipMemsetAsync(s->ph_sums.ptr, 0, 3 * sizeof(unsigned long long), s->stream));
+  hipLaunchKernelGGL(k_count_work, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->ds, d_org, d_dir,
+                     n, s->ph_sums.ptr);
+  HIP_TRY(hipGetLastError());
+  unsigned long long out[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(out, s->ph_sums.ptr, sizeof(out), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (boxes) *boxes = out[0];
+  if (triangles) *triangles = out[1];
+  if (spheres) *spheres = out[2];
+  return RTR_OK;
+}
+
 int rtr_trace_closest(rtr_scene *s, const float *org, const float *dir, size_t n, int32_t *prim,
                       float *t, float *pos, float *nrm) {
   if (!s) return fail(RTR_ERR_INVALID, "scene is null");

@@ -252,6 +252,46 @@ k_trace_api_stream(DeviceScene sc, const float *__restrict__ org, const float *_
   trace_stream(sc, src, sh);
 }
 
+// ---- the algorithmic work of a ray batch ----
+// What the reference's traversal does for each ray, counted: boxes tested (every node the
+// recursion of src/BVH.cpp:66-80 enters), and triangles / spheres tested (leaves whose box
+// the ray's line crosses).  One ray per lane, plain walk; a measurement aid (the traversal
+// kernels above are priced against these counts), not a fast path.
+__global__ void __launch_bounds__(kBlock)
+k_count_work(DeviceScene sc, const float *__restrict__ org, const float *__restrict__ dir, size_t n,
+             unsigned long long *__restrict__ out3) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long boxes = 0, tris = 0, sphs = 0;
+  if (i < n) {
+    const V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    const V3 dn = unit(mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    const GlobalGeom g = global_geom(sc);
+    for (int k = 0; k < sc.n_nodes;) {
+      const float4 lo = g.node_lo(k), hi = g.node_hi(k);
+      const int leaf = (int)wbits(hi);
+      boxes++;
+      if (!slab(lo, hi, o, dn)) {
+        k = (int)wbits(lo);
+      } else if (leaf < 0) {
+        k++;
+      } else {
+        if (leaf >> 30) sphs++; else tris++;
+        k = (int)wbits(lo);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    boxes += __shfl_down(boxes, off);
+    tris += __shfl_down(tris, off);
+    sphs += __shfl_down(sphs, off);
+  }
+  if (lane_id() == 0) {
+    atomicAdd(&out3[0], boxes);
+    atomicAdd(&out3[1], tris);
+    atomicAdd(&out3[2], sphs);
+  }
+}
+
 // ---- Scene::checkConnectable, include/Scene.h:49-56 ----
 // Closest hit from a towards b; connected iff something is hit and its distance is
 // within 1e-3 of |b - a| (the reference's ESP argument is not used by its body).

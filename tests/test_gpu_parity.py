@@ -645,3 +645,28 @@ def test_render_2048_square_image(rt, scenes):
     assert np.allclose(centre, [47.834801, 38.566399, 31.080799], rtol=1e-6)
     # 4096 spp against 64 spp of another seed: same picture, less noise
     assert abs(lum.mean() - (a * lumw).sum(1).mean()) / lum.mean() < 0.01
+
+
+def test_count_work_matches_the_checkers_counters(rt, scenes):
+    """rtr_trace_count_work (what bench.py prices the traversal kernels against) counts the
+    same box / triangle / sphere tests as the instrumented CPU traversal."""
+    import torch
+    O, so, sg = scenes
+    spec = None
+    for scene_o, scene_g, n in ((so, sg, 20000), (None, None, 3000)):
+        if scene_o is None:
+            spec = _random_scene_spec(6, n_tri=700, n_sph=20)
+            scene_o, scene_g = O.build_scene(spec), rt.HostScene.from_spec(spec)
+        org, d = _rays.interior_rays(n, seed=77)
+        O.counters(reset=True)
+        scene_o.intersect(org, d)
+        want = O.counters(reset=True)
+        o_t = torch.from_numpy(org).cuda()
+        d_t = torch.from_numpy(d).cuda()
+        got = scene_g.count_work(o_t.data_ptr(), d_t.data_ptr(), n)
+        assert want[0] == n and tuple(int(x) for x in want[2:4]) == got[1:]
+        # the reference tests a mesh's box twice (as the leaf of the top tree and as the root
+        # of the mesh's own tree, include/Trangle.h:56,99-101); the flattened tree holds it once
+        n_meshes = sum(1 for ob in (spec if scene_o is not so else default_scene_spec())["objects"] if ob[0] == "mesh")
+        assert got[0] <= want[1] <= got[0] + n_meshes * n
+        assert got[0] > 10 * n

@@ -189,3 +189,29 @@ def test_no_device_means_loud_failure(rt):
         sh.intersect(np.zeros((4, 3), f32), np.ones((4, 3), f32))
     with pytest.raises(rt.RtrError):
         sh.render(8, 8, 1)
+
+
+REFERENCE_MAIN = "/root/reference/src/main.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_MAIN), reason="reference checkout not present")
+def test_reference_main_compiles_against_the_host_mirror(tmp_path):
+    """The drop-in claim, checked: the reference's own scene set-up (the body of its main up
+    to the render call, src/main.cpp:7-86, read from the checkout at test time, never kept
+    here) compiles unchanged against rtr_host.hpp and links against the two libraries,
+    followed by the path-tracing call its main has commented out (src/main.cpp:90)."""
+    import subprocess
+    lines = open(REFERENCE_MAIN, encoding="utf-8", errors="replace").read().splitlines()
+    body = "\n".join(lines[6:86])  # lines 7..86: materials, meshes, spheres, camera, scene, renderer
+    assert "scene.rebuildBVH();" in body and "Render renderer;" in body
+    src = tmp_path / "main_from_reference.cpp"
+    src.write_text('#include "rtr_host.hpp"\nint main() {\n' + body +
+                   '\n  renderer.options.devices = {0};\n'
+                   '  renderer.renderPathTracing(scene, 512, 512, 1, "test0");\n'
+                   '  renderer.render(scene, 512, 512, 1, "test0", RenderType::PathTracing);\n'
+                   '  return 0;\n}\n')
+    pkg = os.path.join(ROOT, "raytracingrenderer_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-o", str(tmp_path / "main_from_reference"), str(src),
+                        "-I" + os.path.join(pkg, "host"), "-L" + pkg, "-lrtr_host", "-lrtr_hip",
+                        "-Wl,-rpath," + pkg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
