@@ -670,6 +670,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     sphs[s] = make_float4(d->sph_c[0][s], d->sph_c[1][s], d->sph_c[2][s], d->sph_r[s]);
 
   std::vector<float4> leaves(4 * (leaf_nodes.size() + 1), make_float4(0, 0, 0, 0));  // + padding record
+  int32_t sphere_leaves = 0;  // spheres met so far, in depth-first leaf order
   for (size_t k = 0; k < leaf_nodes.size(); k++) {
     int32_t node = leaf_nodes[k], leaf;
     memcpy(&leaf, &nodes[2 * (size_t)node + 1].w, 4);
@@ -680,6 +681,8 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
       r0 = q;
       r1.x = q.w * q.w;
       r1.y = sqrt_threshold(q.w);
+      memcpy(&r1.z, &sphere_leaves, 4);
+      sphere_leaves++;
     } else {
       float4 q0 = tris[3 * (size_t)row], q1 = tris[3 * (size_t)row + 1], q2 = tris[3 * (size_t)row + 2];
       r0 = q0;

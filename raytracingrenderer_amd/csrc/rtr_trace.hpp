@@ -878,18 +878,33 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
 
 // Geometry staged in LDS by a whole workgroup (kernels call this before tracing,
 // every thread of the block, then __syncthreads()).
-constexpr int kLdsNodes = 64, kLdsTris = 48, kLdsSphs = 32;
+constexpr int kLdsNodes = 64, kLdsTris = 48, kLdsSphs = 32, kLdsLeaves = kLdsTris + kLdsSphs;
 struct LdsScene {
   float4 nodes[2 * kLdsNodes];
   float4 tris[3 * kLdsTris];
   float4 sphs[kLdsSphs];
   int32_t parent[kLdsNodes];
+  // by leaf number k (depth-first leaf order): {node, leaf payload}
+  int2 leaf_of[kLdsLeaves];
+  // by sphere number j (depth-first order among the sphere leaves): {c, r} and
+  // {r*r, T, bits(k), -} of the leaf record (see trace_all)
+  float4 sph_leaf[kLdsSphs], sph_aux[kLdsSphs];
 };
 RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthreads) {
   for (int k = tid; k < 2 * sc.n_nodes; k += nthreads) s.nodes[k] = sc.nodes[k];
   for (int k = tid; k < 3 * sc.n_tris; k += nthreads) s.tris[k] = sc.tris[k];
   for (int k = tid; k < sc.n_sphs; k += nthreads) s.sphs[k] = sc.sphs[k];
   for (int k = tid; k < sc.n_nodes; k += nthreads) s.parent[k] = sc.parent[k];
+  for (int k = tid; k < sc.n_leaves; k += nthreads) {
+    const float4 r0 = sc.leaves[4 * k], r1 = sc.leaves[4 * k + 1], r3 = sc.leaves[4 * k + 3];
+    const int leaf = __float_as_int(r3.w);
+    s.leaf_of[k] = make_int2(__float_as_int(r3.z), leaf);
+    if (leaf >> 30) {
+      const int j = __float_as_int(r1.z);
+      s.sph_leaf[j] = r0;
+      s.sph_aux[j] = make_float4(r1.x, r1.y, __int_as_float(k), 0.0f);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -914,7 +929,8 @@ RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthrea
 //
 // Leaf record, 4 x float4, in depth-first leaf order:
 //   triangle: {p0, n.x} {e1 = p1-p0, n.y} {e2 = p2-p0, n.z} {-, -, bits(node), bits(leaf)}
-//   sphere:   {c, r}    {r*r, T, -, -}    {-}               {-, -, bits(node), bits(leaf)}
+//   sphere:   {c, r}    {r*r, T, bits(j), -}  {-}           {-, -, bits(node), bits(leaf)}
+// (j numbers the sphere leaves in depth-first order.)
 // e1, e2 and r*r are the reference's own fp32 intermediates (src/Trangle.cpp:8-9,
 // src/Sphere.cpp:13), formed once on the host instead of once per ray.  T is the
 // smallest float whose correctly rounded square root is >= r, so that
@@ -1104,32 +1120,49 @@ RTR_DEV int node_of_leaf(const LdsScene &lds, int n_nodes, int leaf) {
   return -1;
 }
 
+// Best hit of one ray while the leaves are folded.  k is the leaf's number in depth-first
+// leaf order (-1: nothing hit yet, with t = +inf).
+struct BestHit {
+  float t, b1, b2;
+  int k;
+  bool nan_seen;
+  RTR_DEV void init() {
+    t = __int_as_float(0x7f800000);
+    b1 = 0; b2 = 0;
+    k = -1;
+    nan_seen = false;
+  }
+  // src/BVH.cpp:75-76 folded left to right -- the best hit is replaced unless it is strictly
+  // nearer -- for leaves that arrive in increasing k: "t <= best" (false for a NaN distance;
+  // best is +inf while nothing is hit, and never NaN).
+  RTR_DEV void fold_next(bool hit, float tt, float bb1, float bb2, int kk) {
+    nan_seen = nan_seen || (hit && tt != tt);
+    const bool take = hit && tt <= t;
+    t = take ? tt : t;
+    b1 = take ? bb1 : b1;
+    b2 = take ? bb2 : b2;
+    k = take ? kk : k;
+  }
+};
+
+// trace_all for two rays that leave the same point, in two phases.
+//
+// 1. One pass over the leaf table (wave-uniform leaf, data in SGPRs, packed arithmetic as
+//    described above).  Triangles are tested and folded.  Of a sphere only the cheap part
+//    runs: does the ray's line meet it at all (origin outside, discriminant >= 0,
+//    src/Sphere.cpp:5-15)?  The answer goes into one bit per sphere and ray.  Few rays
+//    reach a given sphere, but among the 128 rays of a wave nearly always one does, so
+//    running the square root, the two quotients and the fold for the whole wave (as
+//    trace_all does) was mostly idle work.
+// 2. Every lane takes its next marked sphere -- lanes work on different spheres and on
+//    either of their two rays -- reads its record from LDS and finishes the test; the
+//    loop ends when no lane has a mark left (three or four rounds on the default scene,
+//    instead of one per sphere).  Leaves now arrive out of order, so the fold spells the
+//    tie rule out: the reference keeps, among equal distances, the LAST leaf in depth-first
+//    order ("replaced unless strictly nearer"), i.e. the larger k.
 struct HitPair {
   HitRec a, b;
   int node_a, node_b;  // the leaves' node indices (-1 for a miss)
-};
-
-struct BestHit {
-  HitRec h;
-  int node;
-  bool nan_seen;
-  RTR_DEV void init() {
-    h.leaf = -1;
-    h.t = 0; h.b1 = 0; h.b2 = 0;
-    node = -1;
-    nan_seen = false;
-  }
-  // src/BVH.cpp:75-76, folded left to right: replaced unless strictly nearer
-  RTR_DEV void fold(bool hit, float t, float b1, float b2, int leaf, int nd) {
-    const bool is_nan = t != t;
-    nan_seen = nan_seen || (hit && is_nan);
-    const bool take = hit && !is_nan && !(h.leaf >= 0 && h.t < t);
-    h.t = take ? t : h.t;
-    h.b1 = take ? b1 : h.b1;
-    h.b2 = take ? b2 : h.b2;
-    h.leaf = take ? leaf : h.leaf;
-    node = take ? nd : node;
-  }
 };
 
 RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool valid_a, bool valid_b,
@@ -1141,47 +1174,24 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
   const V3x2 ndir = V3x2{-dir.x, -dir.y, -dir.z};
   const f32x2 qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
   const f32x2 qa4 = splat(4.0f) * qa;
-  const bool a_fast = qa.x >= 0.5f && qa.x <= 2.0f && qa.y >= 0.5f && qa.y <= 2.0f;
-  const f32x2 ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
   BestHit ba, bb;
   ba.init();
   bb.init();
+  uint32_t reach_a = 0, reach_b = 0;  // bit j: the ray's line meets sphere j
   LeafRecord r = load_leaf(tab, 0);
   for (int k = 0; k < n_leaves; k++) {
     const LeafRecord nx = load_leaf(tab, k + 1);
-    const int leaf = r.leaf;
-    f32x2 t = splat(0.0f), b1 = t, b2 = t;
-    bool hit_a, hit_b;
-    if (leaf >> 30) {
-      // Sphere::intersect, src/Sphere.cpp:3-39
+    if (r.leaf >> 30) {
+      // Sphere::intersect, src/Sphere.cpp:3-15
       const V3 oc = o - mk(r.a0, r.a1, r.a2);
       const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
       const float cc = l2 - r.b0;
       const bool outside = !(l2 < r.b1);
       const f32x2 b = splat(2.0f) * (splat(oc.x) * dn.x + splat(oc.y) * dn.y + splat(oc.z) * dn.z);
       const f32x2 delta = b * b - qa4 * splat(cc);
-      const bool reach_a = valid_a && outside && !(delta.x < 0);
-      const bool reach_b = valid_b && outside && !(delta.y < 0);
-      hit_a = false;
-      hit_b = false;
-      if (__ballot(reach_a || reach_b) != 0) {
-        const f32x2 sq = f32x2{sqrtf(delta.x), sqrtf(delta.y)};
-        const f32x2 n1 = (-b + sq) / splat(2.0f), n2 = (-b - sq) / splat(2.0f);
-        f32x2 t1, t2;
-        const bool slow = (reach_a && !(quotient_operand_fast(n1.x) && quotient_operand_fast(n2.x))) ||
-                          (reach_b && !(quotient_operand_fast(n1.y) && quotient_operand_fast(n2.y))) ||
-                          ((reach_a || reach_b) && !a_fast);
-        if (__ballot(slow) == 0) {
-          t1 = div_corrected_pairs(n1, qa, ya);
-          t2 = div_corrected_pairs(n2, qa, ya);
-        } else {
-          t1 = f32x2{n1.x / qa.x, n1.y / qa.y};
-          t2 = f32x2{n2.x / qa.x, n2.y / qa.y};
-        }
-        hit_a = reach_a && !(t1.x < kSphEps);
-        hit_b = reach_b && !(t1.y < kSphEps);
-        t = f32x2{(t2.x < 0) ? t1.x : t2.x, (t2.y < 0) ? t1.y : t2.y};
-      }
+      const uint32_t bit = 1u << __float_as_int(r.b2);
+      reach_a |= (valid_a && outside && !(delta.x < 0)) ? bit : 0u;
+      reach_b |= (valid_b && outside && !(delta.y < 0)) ? bit : 0u;
     } else {
       // Trangle::intersect, src/Trangle.cpp:3-28
       const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
@@ -1192,19 +1202,73 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
       const V3x2 s1 = cross(dn, splat(e2));
       const f32x2 se = dot(s1, splat(e1));
       const f32x2 inv = f32x2{1 / se.x, 1 / se.y};
-      t = inv * splat(tnum);
-      b1 = inv * dot(s1, splat(s));
-      b2 = inv * dot(splat(s2), dn);
+      const f32x2 t = inv * splat(tnum);
+      const f32x2 b1 = inv * dot(s1, splat(s));
+      const f32x2 b2 = inv * dot(splat(s2), dn);
       const f32x2 w = splat(1.0f) - b1 - b2;
       const f32x2 facing = dot(ndir, splat(n));
-      hit_a = !(facing.x < 0) &&
-              !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
-      hit_b = !(facing.y < 0) &&
-              !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
+      const bool hit_a = !(facing.x < 0) &&
+                         !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
+      const bool hit_b = !(facing.y < 0) &&
+                         !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
+      ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
+      bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
     }
-    ba.fold(hit_a, t.x, b1.x, b2.x, leaf, r.node);
-    bb.fold(hit_b, t.y, b1.y, b2.y, leaf, r.node);
     r = nx;
+  }
+  // phase 2: the marked spheres, src/Sphere.cpp:3-39
+  for (;;) {
+    const bool on_a = reach_a != 0;
+    const uint32_t m = on_a ? reach_a : reach_b;
+    const bool act = m != 0;
+    if (__ballot(act) == 0) break;
+    const int j = act ? __ffs((int)m) - 1 : 0;
+    if (on_a) reach_a &= reach_a - 1u;
+    else reach_b &= reach_b - 1u;  // 0 stays 0
+    const float4 q = lds.sph_leaf[j], aux = lds.sph_aux[j];
+    const int k = __float_as_int(aux.z);
+    const V3 d = on_a ? dn_a : dn_b;
+    // the arithmetic of phase 1 again, for this lane's ray alone: same operations, same bits
+    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    const V3 oc = o - xyz(q);
+    const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+    const float b = 2 * (oc.x * d.x + oc.y * d.y + oc.z * d.z);
+    const float cc = l2 - aux.x;
+    const float delta = b * b - 4 * a * cc;
+    const bool reach = act && !(l2 < aux.y) && !(delta < 0);
+    const float sq = sqrtf(delta);
+    const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
+    // n / a by two fma corrections of n * RN(1/a) (div_corrected) is the IEEE quotient
+    // when a is in [0.5, 2] and |n| is in [2^-40, 2^40]
+    const bool slow = reach && !(a >= 0.5f && a <= 2.0f && quotient_operand_fast(n1) && quotient_operand_fast(n2));
+    float t1, t2;
+    if (__ballot(slow) == 0) {
+      const float ya = 1.0f / a;
+      t1 = div_corrected(n1, a, ya);
+      t2 = div_corrected(n2, a, ya);
+    } else {
+      t1 = n1 / a;
+      t2 = n2 / a;
+    }
+    const bool hit = reach && !(t1 < kSphEps);
+    const float t = (t2 < 0) ? t1 : t2;
+    const bool is_nan = t != t;
+    ba.nan_seen = ba.nan_seen || (hit && is_nan && on_a);
+    bb.nan_seen = bb.nan_seen || (hit && is_nan && !on_a);
+    const float bt = on_a ? ba.t : bb.t;
+    const int bk = on_a ? ba.k : bb.k;
+    const bool take = hit && (t < bt || (t == bt && k > bk));  // false for a NaN distance
+    const bool ta = take && on_a, tb = take && !on_a;
+    ba.t = ta ? t : ba.t; ba.b1 = ta ? 0.0f : ba.b1; ba.b2 = ta ? 0.0f : ba.b2; ba.k = ta ? k : ba.k;
+    bb.t = tb ? t : bb.t; bb.b1 = tb ? 0.0f : bb.b1; bb.b2 = tb ? 0.0f : bb.b2; bb.k = tb ? k : bb.k;
+  }
+  HitPair out;
+  {
+    const int2 la = lds.leaf_of[ba.k >= 0 ? ba.k : 0], lb = lds.leaf_of[bb.k >= 0 ? bb.k : 0];
+    out.a = HitRec{ba.k >= 0 ? ba.t : 0.0f, ba.b1, ba.b2, ba.k >= 0 ? la.y : -1};
+    out.b = HitRec{bb.k >= 0 ? bb.t : 0.0f, bb.b1, bb.b2, bb.k >= 0 ? lb.y : -1};
+    out.node_a = ba.k >= 0 ? la.x : -1;
+    out.node_b = bb.k >= 0 ? lb.x : -1;
   }
   // both winners' boxes: the leaf's own box, or leaf to root (see trace_all)
   const bool fast = sc.fast_planes != 0 && fast_ray(o, dn_a) && fast_ray(o, dn_b);
@@ -1212,7 +1276,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
   const V3 inv_a = mk(1.0f / dn_a.x, 1.0f / dn_a.y, 1.0f / dn_a.z);
   const V3 inv_b = mk(1.0f / dn_b.x, 1.0f / dn_b.y, 1.0f / dn_b.z);
   bool ok_a = true, ok_b = true;
-  int na = ba.node, nb = bb.node;
+  int na = out.node_a, nb = out.node_b;
   while (na >= 0 || nb >= 0) {
     // a finished chain re-tests the root: harmless, and keeps the loop body straight
     const int ia = na >= 0 ? na : 0, ib = nb >= 0 ? nb : 0;
@@ -1231,7 +1295,6 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     na = (na >= 0 && !leaf_only) ? lds.parent[ia] : -1;
     nb = (nb >= 0 && !leaf_only) ? lds.parent[ib] : -1;
   }
-  HitPair out{ba.h, bb.h, ba.node, bb.node};
   unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
   unsigned long long need_b = __ballot(valid_b && (bb.nan_seen || !ok_b));
   if (need_a | need_b) {
