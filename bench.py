@@ -353,7 +353,7 @@ def main():
                                          "other": agg["ms_other"] / args.steps},
             "roofline": roofline,
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the reference's wall ends with the framebuffer on the host: the same render
             # through the host-output entry point (one D2H copy more)
             try:

@@ -180,6 +180,15 @@ typedef struct rtr_stats {
 const char *rtr_last_error(void);
 int rtr_device_count(int *n);
 
+/*
+ * Device self-test of the arithmetic shortcuts the kernels take where the reference
+ * divides (no counterpart in the reference): the short reciprocal sequence used by the
+ * triangle test is compared with the IEEE quotient 1.0f / d for all 2^32 floats.
+ * *mismatches = number of differing results; anything but 0 means this toolchain or
+ * device does not reproduce the reference's arithmetic and results are not to be trusted.
+ */
+int rtr_self_test(int device, uint64_t *mismatches);
+
 /* Uploads the scene to `device` (copies everything; the desc may be freed). */
 int rtr_scene_create(const rtr_scene_desc *desc, int device, rtr_scene **out);
 void rtr_scene_destroy(rtr_scene *scene);

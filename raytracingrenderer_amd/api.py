@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
     "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
-    "rtr_render_pt_multi_device", "rtr_trace_count_work",
+    "rtr_render_pt_multi_device", "rtr_trace_count_work", "rtr_self_test",
 ]
 
 _hip = None
@@ -175,6 +175,15 @@ def device_count():
     n = C.c_int32(0)
     rc = hip_lib().rtr_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def self_test(device=0):
+    """rtr_self_test: number of mismatches of the kernels' arithmetic shortcuts (must be 0)."""
+    n = C.c_uint64(0)
+    L = hip_lib()
+    L.rtr_self_test.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    _check(L.rtr_self_test(device, C.byref(n)), "rtr_self_test")
+    return n.value
 
 
 def partition_columns(width, part_index, part_count, tile_cols=8):

@@ -884,6 +884,28 @@ int rtr_trace_closest_device(rtr_scene *s, const float *d_org, const float *d_di
   return RTR_OK;
 }
 
+int rtr_self_test(int device, uint64_t *mismatches) {
+  if (!mismatches) return fail(RTR_ERR_INVALID, "mismatches is null");
+  *mismatches = 0;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RTR_ERR_INVALID, "device index out of range");
+  DeviceGuard guard(device);
+  unsigned long long *d_bad = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_bad, sizeof(*d_bad)));
+  hipError_t e = hipMemset(d_bad, 0, sizeof(*d_bad));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_reciprocal, dim3(65536), dim3(kBlock), 0, nullptr, d_bad);
+    e = hipGetLastError();
+  }
+  unsigned long long bad = 0;
+  if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+  (void)hipFree(d_bad);
+  HIP_TRY(e);
+  *mismatches = bad;
+  return RTR_OK;
+}
+
 int rtr_trace_count_work(rtr_scene *s, const float *d_org, const float *d_dir, size_t n,
                          uint64_t *boxes, uint64_t *triangles, uint64_t *spheres) {
   if (!s) return fail(RTR_ERR_INVALID, "scene is null");

@@ -252,6 +252,24 @@ k_trace_api_stream(DeviceScene sc, const float *__restrict__ org, const float *_
   trace_stream(sc, src, sh);
 }
 
+// ---- self-test of the exact-arithmetic shortcuts ----
+// reciprocal_pair against the IEEE division for every float: workgroup b covers the 2^16
+// bit patterns b * 65536 ... (launched with 65536 workgroups of 256 threads).
+__global__ void __launch_bounds__(kBlock)
+k_selftest_reciprocal(unsigned long long *__restrict__ mismatches) {
+  unsigned bad = 0;
+  for (unsigned k = 0; k < 256u; k += 2u) {
+    const uint32_t u = blockIdx.x * 65536u + k * 256u + threadIdx.x;
+    const f32x2 d = {__uint_as_float(u), __uint_as_float(u + 256u)};
+    const f32x2 got = reciprocal_pair(d);
+    const float w0 = 1.0f / d.x, w1 = 1.0f / d.y;
+    // any NaN equals any NaN
+    bad += (__float_as_uint(got.x) != __float_as_uint(w0) && !(got.x != got.x && w0 != w0)) ? 1u : 0u;
+    bad += (__float_as_uint(got.y) != __float_as_uint(w1) && !(got.y != got.y && w1 != w1)) ? 1u : 0u;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // ---- the algorithmic work of a ray batch ----
 // What the reference's traversal does for each ray, counted: boxes tested (every node the
 // recursion of src/BVH.cpp:66-80 enters), and triangles / spheres tested (leaves whose box

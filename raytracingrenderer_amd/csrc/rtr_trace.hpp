@@ -255,6 +255,30 @@ RTR_DEV f32x2 div_corrected2(f32x2 a, float d, float y) {
   return __builtin_elementwise_fma(r, yy, q);
 }
 
+// RN(1/d) without the range handling of an IEEE division.  hipcc expands 1.0f / d into
+// v_div_scale (twice), v_rcp, six fma steps, v_div_fmas and v_div_fixup; for a normal d
+// that is neither tiny nor huge the scaling steps scale by one and the fix-up passes the
+// quotient through, so the six fma steps on their own give the same bits:
+//   y0 = rcp(d); y1 = y0 + (1 - d y0) y0; q1 = y1 + (1 - d y1) y1; q = q1 + (1 - d q1) y1.
+// Precondition |d| in [2^-60, 2^60] (reciprocal_operand_fast); the self-test entry point
+// compares it with 1.0f / d for every float.
+RTR_DEV bool reciprocal_operand_fast(float d) {
+  const float m = fabsf(d);
+  return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // 2^-60, 2^60
+}
+RTR_DEV float reciprocal_fast(float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float y1 = __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-d, y1, 1.0f), y1, y1);
+  return __builtin_fmaf(__builtin_fmaf(-d, q1, 1.0f), y1, q1);
+}
+// 1.0f / d, by the short sequence when every lane of the wave may take it
+RTR_DEV f32x2 reciprocal_pair(f32x2 d) {
+  const bool slow = !(reciprocal_operand_fast(d.x) && reciprocal_operand_fast(d.y));
+  if (__ballot(slow) == 0) return f32x2{reciprocal_fast(d.x), reciprocal_fast(d.y)};
+  return f32x2{1 / d.x, 1 / d.y};
+}
+
 RTR_DEV bool slab_fast(float4 lo, float4 hi, V3 o, V3 d, V3 y) {
   const f32x2 px = {lo.x, hi.x}, py = {lo.y, hi.y}, pz = {lo.z, hi.z};
   const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
@@ -1177,7 +1201,13 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
   BestHit ba, bb;
   ba.init();
   bb.init();
-  uint32_t reach_a = 0, reach_b = 0;  // bit j: the ray's line meets sphere j
+  uint32_t reach_a = 0, reach_b = 0;  // bit j: the ray's line meets sphere j, not behind the origin
+  const bool a_half = qa.x >= 0.5f && qa.y >= 0.5f;
+  // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
+  // when qa is in [0.5, 2] and |n| is in [2^-40, 2^40]
+  const bool a_fast = a_half && qa.x <= 2.0f && qa.y <= 2.0f;
+  f32x2 ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
+  asm volatile("" : "+v"(ya));  // formed once here, not again in every round of phase 2
   LeafRecord r = load_leaf(tab, 0);
   for (int k = 0; k < n_leaves; k++) {
     const LeafRecord nx = load_leaf(tab, k + 1);
@@ -1190,9 +1220,16 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
       const f32x2 b = splat(2.0f) * (splat(oc.x) * dn.x + splat(oc.y) * dn.y + splat(oc.z) * dn.z);
       const f32x2 delta = b * b - qa4 * splat(cc);
       const uint32_t bit = 1u << __float_as_int(r.b2);
-      reach_a |= (valid_a && outside && !(delta.x < 0)) ? bit : 0u;
-      reach_b |= (valid_b && outside && !(delta.y < 0)) ? bit : 0u;
+      // A sphere behind the ray needs no second look: with the origin outside (cc > 0) and
+      // b > 0 the larger root is negative or a rounding error above zero -- sqrt(delta) is at
+      // most one ulp above b, so for b < 8192 and a >= 0.5 the root is below 2^-11 < 1e-3
+      // and the reference's `t1 < 1e-3` (src/Sphere.cpp:19) rejects it.
+      const bool behind_a = cc > 0 && b.x > 0 && b.x < 8192.0f && a_half;
+      const bool behind_b = cc > 0 && b.y > 0 && b.y < 8192.0f && a_half;
+      reach_a |= (valid_a && outside && !(delta.x < 0) && !behind_a) ? bit : 0u;
+      reach_b |= (valid_b && outside && !(delta.y < 0) && !behind_b) ? bit : 0u;
     } else {
+#ifndef RTR_ABL_NO_TRI
       // Trangle::intersect, src/Trangle.cpp:3-28
       const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
       const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
@@ -1201,7 +1238,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
       const float tnum = dot(s2, e2);
       const V3x2 s1 = cross(dn, splat(e2));
       const f32x2 se = dot(s1, splat(e1));
-      const f32x2 inv = f32x2{1 / se.x, 1 / se.y};
+      const f32x2 inv = reciprocal_pair(se);
       const f32x2 t = inv * splat(tnum);
       const f32x2 b1 = inv * dot(s1, splat(s));
       const f32x2 b2 = inv * dot(splat(s2), dn);
@@ -1211,17 +1248,32 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
                          !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
       const bool hit_b = !(facing.y < 0) &&
                          !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
+#ifndef RTR_ABL_NO_FOLD
       ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
       bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
+#else
+      if (k == 1) { ba.fold_next(hit_a || t.x > 1e30f, t.x, b1.x, b2.x, k); bb.fold_next(hit_b || t.y > 1e30f, t.y, b1.y, b2.y, k); }
+      else { ba.nan_seen |= hit_a && t.x == 12345.f; bb.nan_seen |= hit_b && t.y == 12345.f; }
+#endif
+#endif
     }
     r = nx;
   }
+#ifdef RTR_ABL_NO_PHASE2
+  reach_a = reach_b = 0;
+#endif
+  RTR_STAT(0, 1);
+  RTR_STAT(3, __popcll(__ballot(valid_a)));
+  RTR_STAT(4, __popcll(__ballot(valid_b)));
+  RTR_STAT(5, __popcll(__ballot(valid_a || valid_b)));
   // phase 2: the marked spheres, src/Sphere.cpp:3-39
   for (;;) {
     const bool on_a = reach_a != 0;
     const uint32_t m = on_a ? reach_a : reach_b;
     const bool act = m != 0;
     if (__ballot(act) == 0) break;
+    RTR_STAT(1, 1);
+    RTR_STAT(2, __popcll(__ballot(act)));
     const int j = act ? __ffs((int)m) - 1 : 0;
     if (on_a) reach_a &= reach_a - 1u;
     else reach_b &= reach_b - 1u;  // 0 stays 0
@@ -1229,7 +1281,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     const int k = __float_as_int(aux.z);
     const V3 d = on_a ? dn_a : dn_b;
     // the arithmetic of phase 1 again, for this lane's ray alone: same operations, same bits
-    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float a = on_a ? qa.x : qa.y;
     const V3 oc = o - xyz(q);
     const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
     const float b = 2 * (oc.x * d.x + oc.y * d.y + oc.z * d.z);
@@ -1238,14 +1290,12 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     const bool reach = act && !(l2 < aux.y) && !(delta < 0);
     const float sq = sqrtf(delta);
     const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
-    // n / a by two fma corrections of n * RN(1/a) (div_corrected) is the IEEE quotient
-    // when a is in [0.5, 2] and |n| is in [2^-40, 2^40]
-    const bool slow = reach && !(a >= 0.5f && a <= 2.0f && quotient_operand_fast(n1) && quotient_operand_fast(n2));
+    const bool slow = reach && !(a_fast && quotient_operand_fast(n1) && quotient_operand_fast(n2));
     float t1, t2;
     if (__ballot(slow) == 0) {
-      const float ya = 1.0f / a;
-      t1 = div_corrected(n1, a, ya);
-      t2 = div_corrected(n2, a, ya);
+      const float y = on_a ? ya.x : ya.y;
+      t1 = div_corrected(n1, a, y);
+      t2 = div_corrected(n2, a, y);
     } else {
       t1 = n1 / a;
       t2 = n2 / a;

@@ -670,3 +670,8 @@ def test_count_work_matches_the_checkers_counters(rt, scenes):
         n_meshes = sum(1 for ob in (spec if scene_o is not so else default_scene_spec())["objects"] if ob[0] == "mesh")
         assert got[0] <= want[1] <= got[0] + n_meshes * n
         assert got[0] > 10 * n
+
+
+def test_device_self_test_of_arithmetic_shortcuts(rt):
+    """The short reciprocal sequence of the triangle test equals 1.0f / d for every float."""
+    assert rt.self_test(0) == 0
