@@ -896,6 +896,18 @@ struct UnitState {
   uint32_t fmat[kBlock], out[kBlock], k_end[kBlock];  // out: index of the unit's partial sum
 };
 
+// Kernel arguments that are only needed when a lane takes a new work unit or finishes one
+// (once in a dozen rounds or more): kept in LDS, so that they do not hold scalar registers
+// through the sampling loop -- the loop needs all of them for leaf records and lane masks,
+// and what does not fit is spilled into lanes of a vector register.
+struct ColdArgs {
+  PixelCache pc;
+  const uint32_t *shade_list;
+  float4 *partial;
+  Counters *fc;
+  uint32_t n_pix, chunk_spp, spp;
+};
+
 // prim id, material and emissive flag of a hit
 template <bool kLds>
 RTR_DEV void hit_info(const DeviceScene &sc, const DeviceMaterial *__restrict__ mats,
@@ -949,6 +961,17 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
   }
   typename WaveLds<kLds>::type &ws = wsh[tid >> 6];
   us.k_end[tid] = 0;
+  __shared__ ColdArgs cold;
+  if (tid == 0) {
+    cold.pc = pc;
+    cold.shade_list = shade_list;
+    cold.partial = partial;
+    cold.fc = fc;
+    cold.n_pix = (uint32_t)a.n_pix;
+    cold.chunk_spp = (uint32_t)a.chunk_spp;
+    cold.spp = (uint32_t)a.spp;
+  }
+  __syncthreads();
   // the number of pixels that need sampling comes straight from the classification
   // kernel's counter: the host does not wait for it between the two launches
   const uint32_t n_shade = __atomic_load_n(&fc->n_shade, __ATOMIC_RELAXED);
@@ -968,7 +991,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if (!live) {
       if (has_unit && k >= us.k_end[tid]) {
         const V3 acc = mk(us.acc[0][tid], us.acc[1][tid], us.acc[2][tid]);
-        partial[us.out[tid]] = pack(acc, 0.0f);
+        cold.partial[us.out[tid]] = pack(acc, 0.0f);
         has_unit = false;
       }
     }
@@ -978,7 +1001,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       if (res_left == 0) {
         if (drained) break;
         unsigned long long base = 0;
-        if (lane_id() == 0) base = atomicAdd(&fc->next_unit, 64ull);
+        if (lane_id() == 0) base = atomicAdd(&cold.fc->next_unit, 64ull);
         base = __shfl(base, 0);
         if (base >= n_units) {
           drained = true;
@@ -992,16 +1015,16 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         const uint32_t u = res_base + rank;
         const uint32_t entry = u % n_shade;
         const uint32_t chunk = u / n_shade;
-        const uint32_t lp = shade_list[entry];
-        const float4 pm = pc.pos_mat[lp], pn = pc.nrm[lp], pw = pc.wi[lp];
+        const uint32_t lp = cold.shade_list[entry];
+        const float4 pm = cold.pc.pos_mat[lp], pn = cold.pc.nrm[lp], pw = cold.pc.wi[lp];
         us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
         us.fmat[tid] = wbits(pm);
         us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
         us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
         gpix = wbits(pw);
-        us.out[tid] = chunk * (uint32_t)a.n_pix + lp;  // below 2^32: checked by the host
-        k = chunk * (uint32_t)a.chunk_spp;
-        us.k_end[tid] = min((uint32_t)a.spp, k + (uint32_t)a.chunk_spp);
+        us.out[tid] = chunk * cold.n_pix + lp;  // below 2^32: checked by the host
+        k = chunk * cold.chunk_spp;
+        us.k_end[tid] = min(cold.spp, k + cold.chunk_spp);
         us.acc[0][tid] = 0; us.acc[1][tid] = 0; us.acc[2][tid] = 0;
         has_unit = true;
       }

@@ -1229,7 +1229,6 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
       reach_a |= (valid_a && outside && !(delta.x < 0) && !behind_a) ? bit : 0u;
       reach_b |= (valid_b && outside && !(delta.y < 0) && !behind_b) ? bit : 0u;
     } else {
-#ifndef RTR_ABL_NO_TRI
       // Trangle::intersect, src/Trangle.cpp:3-28
       const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
       const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
@@ -1248,20 +1247,11 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
                          !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
       const bool hit_b = !(facing.y < 0) &&
                          !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
-#ifndef RTR_ABL_NO_FOLD
       ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
       bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
-#else
-      if (k == 1) { ba.fold_next(hit_a || t.x > 1e30f, t.x, b1.x, b2.x, k); bb.fold_next(hit_b || t.y > 1e30f, t.y, b1.y, b2.y, k); }
-      else { ba.nan_seen |= hit_a && t.x == 12345.f; bb.nan_seen |= hit_b && t.y == 12345.f; }
-#endif
-#endif
     }
     r = nx;
   }
-#ifdef RTR_ABL_NO_PHASE2
-  reach_a = reach_b = 0;
-#endif
   RTR_STAT(0, 1);
   RTR_STAT(3, __popcll(__ballot(valid_a)));
   RTR_STAT(4, __popcll(__ballot(valid_b)));
