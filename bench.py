@@ -87,13 +87,13 @@ def cpu_baseline(W, H):
             "kind": "port", "sample": "%dx%d at %d spp, %.1f s (%s)" % (W, H, spp, dt, model)}
 
 
-def timed_render(torch, scene, W, H, spp, dev, **kw):
+def timed_render(torch, scene, W, H, spp, dev, profile=True, **kw):
     """One render into a device buffer, after a short one that sizes the workspace."""
     buf = torch.empty(W * H * 3, dtype=torch.float32, device=dev)
     scene.render_device(W, H, max(1, spp // 64), buf.data_ptr(), **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    st = scene.render_device(W, H, spp, buf.data_ptr(), profile=True, **kw)
+    st = scene.render_device(W, H, spp, buf.data_ptr(), profile=profile, **kw)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"msamples_per_s": W * H * spp / dt / 1e6, "ms": dt * 1e3, "mrays_per_s_unique": st.rays / dt / 1e6,
@@ -101,7 +101,8 @@ def timed_render(torch, scene, W, H, spp, dev, **kw):
             "mode": "fused" if st.mode == 2 else "wavefront", "chunk_spp": st.chunk_spp,
             "kernel_ms": {"fused": st.ms_fused, "trace": st.ms_trace, "logic": st.ms_logic,
                           "other": st.ms_other},
-            "iterations": st.iterations}
+            "iterations": st.iterations, "boxes_tested": st.boxes_tested, "prims_tested": st.prims_tested,
+            "queue_rays": st.rays - st.samples // max(1, spp)}
 
 
 def extras(torch, rt, dev, seed):
@@ -173,8 +174,15 @@ def extras(torch, rt, dev, seed):
                                           "Cache, so the bytes are served by L2 / Infinity Cache / HBM "
                                           "together: the bound is the memory fabric, priced at the HBM peak"}}}
     del o_t, d_t, prim, t
-    r = timed_render(torch, sm, 784, 784, 64, dev, seed=seed)
-    rec["render_784x784_64spp"] = r
+    # (no per-kernel events here: they would keep the two streams of the loop from overlapping)
+    r = timed_render(torch, sm, 784, 784, 256, dev, profile=False, seed=seed)
+    # the render's rays are heavier than the isotropic test rays above: bytes counted per render
+    rb = 32.0 * r["boxes_tested"] + 48.0 * r["prims_tested"] + 36.0 * r["queue_rays"]
+    r["roofline"] = {"kernel": "k_trace_queue_stream (whole render: path logic, pool fill and drain included)",
+                     "bound": "hbm", "achieved": rb / (r["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": rb / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                     "bytes_per_ray": rb / max(1, r["queue_rays"])}
+    rec["render_784x784_256spp"] = r
     out.append(rec)
     sm.close()
     return out

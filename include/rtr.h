@@ -175,6 +175,9 @@ typedef struct rtr_stats {
   double ms_gather;        /* rtr_render_pt_multi: last partition rendered -> whole image in place */
   int32_t n_devices;       /* partitions rendered concurrently (1 for the single-device calls) */
   int32_t reserved;
+  /* wavefront loop on scenes read from memory: box tests and primitive tests its traversal
+     launches made (the primary rays' launch not included); 0 elsewhere */
+  uint64_t boxes_tested, prims_tested;
 } rtr_stats;
 
 const char *rtr_last_error(void);

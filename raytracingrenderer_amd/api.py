@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("ms_trace", C.c_double), ("ms_logic", C.c_double), ("ms_other", C.c_double),
                 ("trace_launches", C.c_uint64), ("ms_fused", C.c_double),
                 ("fused_launches", C.c_uint64), ("ms_gather", C.c_double),
-                ("n_devices", C.c_int32), ("reserved", C.c_int32)]
+                ("n_devices", C.c_int32), ("reserved", C.c_int32),
+                ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64)]
 
 
 class Camera(C.Structure):

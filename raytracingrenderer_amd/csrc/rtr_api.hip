@@ -1338,7 +1338,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     }
   }
   if (int rc = enqueue_resolve(pl, rb, d_rgb, st, ev)) return rc;
-  if (fused) HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ws.host_counters, cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   ev.harvest();
   if (fused) {
@@ -1361,6 +1361,8 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     stats->ms_fused = ev.ms[kSpanFused];
     stats->fused_launches = fused_launches;
     stats->n_devices = 1;
+    stats->boxes_tested = ws.host_counters->boxes;
+    stats->prims_tested = ws.host_counters->prims;
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   }
@@ -1565,6 +1567,8 @@ static int render_multi(rtr_scene *const *scenes, int32_t n_scenes, const rtr_ca
       stats->vertices += k.st.vertices;
       stats->trace_launches += k.st.trace_launches;
       stats->fused_launches += k.st.fused_launches;
+      stats->boxes_tested += k.st.boxes_tested;
+      stats->prims_tested += k.st.prims_tested;
       stats->iterations = std::max(stats->iterations, k.st.iterations);
       // kernel times: the slowest partition's, which is what the image waited for
       stats->ms_trace = std::max(stats->ms_trace, k.st.ms_trace);

@@ -70,6 +70,11 @@ struct Counters {
   // cursors of k_trace_queue_stream over the (workgroup, ray kind) queue segments of a
   // launch, one per half of the pool; k_logic resets the one of its half
   unsigned int trace_next[2];
+  // rays queued by the k_logic launch of [half of the pool][iteration parity]: lets the
+  // traversal kernel see how full the queue segments of its launch are
+  unsigned int queued[2][2];
+  // work of the streaming traversal launches of a render: box tests, primitive tests
+  unsigned long long boxes, prims;
 };
 
 // The wavefront loop's only global atomic is the unit cursor (one add per 64 units).
@@ -221,6 +226,7 @@ struct RayArrays {
     const unsigned long long left = n - b;
     return left < 64 ? (unsigned)left : 64u;
   }
+  RTR_DEV void report(unsigned long long, unsigned long long) const {}
   RTR_DEV void load(Index i, V3 &o, V3 &d, Tag &tag) const {
     o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
@@ -355,6 +361,7 @@ struct ConnectPairs {
     const unsigned long long left = n - b;
     return left < 64 ? (unsigned)left : 64u;
   }
+  RTR_DEV void report(unsigned long long, unsigned long long) const {}
   RTR_DEV V3 span(Index i, V3 &a) const {
     a = mk(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
     return mk(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]) - a;
@@ -477,21 +484,47 @@ struct QueueRays {
   unsigned int *next;
   int parity;
   unsigned blk_begin, n_pairs;  // first k_logic workgroup of the launch; 2 x their number
+  // A wave reserves `take` consecutive (workgroup, ray kind) segments with one atomic add and
+  // works through the non-empty ones.  take = 1 while segments are full (finest balance: rays
+  // differ in cost by orders of magnitude); when most are empty -- the last iterations of a
+  // render, when few paths are left -- a single counter handed out one segment at a time is
+  // what a launch waits for (16 K atomic adds in a row on one address: 0.25 ms for no rays),
+  // so the reservation grows to up to 64.
+  unsigned take;
   unsigned pos, end;            // wave-uniform: unread entries of the current segment
+  unsigned long long pending;   // reserved segments with rays, not started yet (bit = lane)
+  unsigned my_pos, my_cnt;      // lane l: segment l of the reservation
+  Counters *totals;
+  RTR_DEV void report(unsigned long long boxes, unsigned long long prims) const {
+    if (lane_id() == 0 && boxes) {
+      atomicAdd(&totals->boxes, boxes);
+      atomicAdd(&totals->prims, prims);
+    }
+  }
   RTR_DEV unsigned grab(Index &base, bool &more) {
     while (pos == end) {
-      unsigned w = 0;
-      if (lane_id() == 0) w = atomicAdd(next, 1u);
-      w = wave_first(w);
-      if (w >= n_pairs) {
-        more = false;
-        return 0;
+      if (pending == 0) {
+        unsigned w = 0;
+        if (lane_id() == 0) w = atomicAdd(next, take);
+        w = wave_first(w);
+        if (w >= n_pairs) {
+          more = false;
+          return 0;
+        }
+        const unsigned idx = w + lane_id();
+        const unsigned b = blk_begin + (idx >> 1), kind = idx & 1u;
+        unsigned c = 0;
+        if (lane_id() < take && idx < n_pairs) c = bc[b].qcount[parity][kind];
+        if (c) bc[b].rays[kind] += c;  // only writer
+        my_pos = b * (unsigned)kSegment + kind * (unsigned)kLogicBlock;
+        my_cnt = c;
+        pending = __ballot(c != 0);
+        continue;
       }
-      const unsigned b = blk_begin + (w >> 1), kind = w & 1u;
-      const unsigned c = wave_first(bc[b].qcount[parity][kind]);
-      if (lane_id() == 0 && c) bc[b].rays[kind] += c;  // only writer
-      pos = b * (unsigned)kSegment + kind * (unsigned)kLogicBlock;
-      end = pos + c;
+      const int l = __ffsll((long long)pending) - 1;
+      pending &= pending - 1;
+      pos = (unsigned)__builtin_amdgcn_readlane((int)my_pos, l);
+      end = pos + (unsigned)__builtin_amdgcn_readlane((int)my_cnt, l);
     }
     base = pos;
     const unsigned got = end - pos < 64u ? end - pos : 64u;
@@ -526,7 +559,12 @@ k_trace_queue_stream(DeviceScene sc, PathPool p, const uint32_t *__restrict__ qu
   __shared__ StreamShared sh;
   if (threadIdx.x == 0) sh.merge_lock = 0;
   __syncthreads();
-  QueueRays src{sc, p, queue, bc, &cnt->trace_next[blk_begin != 0], parity, blk_begin, 2 * n_blk, 0, 0};
+  // average filling of the launch's segments (each holds up to kLogicBlock rays)
+  const unsigned n_pairs = 2 * n_blk;
+  const unsigned queued = wave_first(cnt->queued[blk_begin != 0][parity]);
+  const unsigned per_pair = queued / n_pairs;
+  const unsigned take = per_pair >= 64u ? 1u : per_pair >= 16u ? 4u : per_pair >= 4u ? 16u : 64u;
+  QueueRays src{sc, p, queue, bc, &cnt->trace_next[blk_begin != 0], parity, blk_begin, n_pairs, take, 0, 0, 0ull, 0, 0, cnt};
   trace_stream(sc, src, sh);
 }
 
@@ -649,7 +687,10 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
         Counters *__restrict__ cnt, uint2 *__restrict__ wave_res, int parity, int block_off) {
   __shared__ unsigned s_count[4][kLogicWaves];
   const int blk = (int)blockIdx.x + block_off;  // the pool may be driven as several launches
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->trace_next[block_off != 0] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cnt->trace_next[block_off != 0] = 0;
+    cnt->queued[block_off != 0][parity ^ 1] = 0;  // its reader, the previous traversal launch, is over
+  }
   const int slot = blk * kLogicBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
   const bool in_range = slot < a.pool;
@@ -846,6 +887,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
     BlockCounters &b = bc[blk];
     b.qcount[parity][0] = sh_total;
     b.qcount[parity][1] = ext_total;
+    if (sh_total + ext_total) atomicAdd(&cnt->queued[block_off != 0][parity], sh_total + ext_total);
     if (a.first) { b.done = nf; b.vertices = nl; b.rays[0] = 0; b.rays[1] = 0; b.qcount[parity ^ 1][0] = 0; b.qcount[parity ^ 1][1] = 0; }
     else { b.done += nf; b.vertices += nl; }
   }

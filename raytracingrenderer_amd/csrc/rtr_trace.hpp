@@ -673,6 +673,7 @@ RTR_DEV unsigned long long lane_read(unsigned long long v, unsigned src_lane) {
 //       when nothing is left beyond them (only then may n be 0);
 //   void load(Index idx, V3 &o, V3 &dir, Tag &tag) -- ray idx and whatever names its
 //       result slot (Tag is a 4- or 8-byte integer);
+//   void report(boxes, prims) -- once per wave at the end: box tests and primitive tests it made;
 //   void store(Tag tag, int leaf, float t, V3 pos, V3 nrm) -- the result: leaf is -1
 //       for a miss, else (kind << 30) | row with the hit's distance, position and normal
 //       (Intersection::postion / ::normal of src/Trangle.cpp:23-24, src/Sphere.cpp:25-26).
@@ -707,6 +708,8 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
   V3 so = mk(0, 0, 0), sd = mk(1, 1, 1);
   Tag stag = 0;
   int i = 0, end = 0;
+  // the wave's work, counted in scalar registers: boxes tested, primitives tested
+  unsigned long long n_boxes = 0, n_prims = 0;
   for (;;) {
     const bool alive = i < end;
     const unsigned long long alive_mask = __ballot(alive);
@@ -720,6 +723,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
       // flush the pending primitive tests, so that finished rays are final
       {
         const unsigned c0 = tail0 - head0, c1 = tail1 - head1;
+        n_prims += c0 + c1;
         RTR_STAT(4, (c0 + c1 > 64u) ? 2 : (c0 + c1 > 0u ? 1 : 0));
         RTR_STAT(5, c0 + c1);
         if (c0 + c1 > 64u) {
@@ -854,6 +858,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
       if ((__ballot(have) | __ballot(i < end)) == 0) break;  // stream dry, nothing in flight
       continue;
     }
+    n_boxes += n_alive;
     RTR_STAT(0, 1);
     RTR_STAT(1, n_alive);
     bool cand = false;
@@ -882,6 +887,7 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
       if (tail0 - head0 >= 64u) {
         RTR_STAT(4, 1);
         RTR_STAT(5, 64);
+        n_prims += 64u;
         stream_round(sc, ws, head0, 64u, head1, 0u);
         head0 += 64u;
       }
@@ -893,11 +899,13 @@ RTR_DEV void trace_stream(const DeviceScene &sc, Src &src, StreamShared &sh) {
       if (tail1 - head1 >= 64u) {
         RTR_STAT(4, 1);
         RTR_STAT(5, 64);
+        n_prims += 64u;
         stream_round(sc, ws, head0, 0u, head1, 64u);
         head1 += 64u;
       }
     }
   }
+  src.report(n_boxes, n_prims);
 }
 
 // Geometry staged in LDS by a whole workgroup (kernels call this before tracing,

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Kernel trace of the wavefront loop on the 1 M-triangle scene (tools/mesh_render_once.py):
+# per-kernel statistics, and from the per-dispatch time stamps how much of the render's
+# span the GPU spent in which kernel and how much of it nothing ran.
+# usage (on the GPU box): tools/profile_mesh_render.sh <label> [spp] [streams]
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_mesh_render_${1:-r02}
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o mesh -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > $OUT/render.txt 2> $OUT/ktrace.log || { tail -5 $OUT/ktrace.log; exit 1; }
+python3 - <<PY
+import csv, glob, os, collections
+out = "$OUT"
+for f in glob.glob(os.path.join(out, "ktrace", "**", "*kernel_stats.csv"), recursive=True):
+    open(os.path.join(out, "mesh_render_kernel_stats.csv"), "w").write(open(f).read())
+    print(open(f).read())
+rows = []
+for f in glob.glob(os.path.join(out, "ktrace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")))
+rows.sort()
+# the timed render: everything after the last k_raygen
+start = max(i for i, r in enumerate(rows) if "k_raygen" in r[2])
+rows = rows[start:]
+t0, t1 = rows[0][0], max(r[1] for r in rows)
+busy = collections.defaultdict(int)
+ev = []
+for a, b, k in rows:
+    busy[k] += b - a
+    ev += [(a, 1), (b, -1)]
+ev.sort()
+depth, last, idle, two = 0, t0, 0, 0
+for t, d in ev:
+    if depth == 0: idle += t - last
+    if depth >= 2: two += t - last
+    depth += d
+    last = t
+lines = ["span of the render %.2f ms, no kernel running %.2f ms, two or more kernels running %.2f ms, %d dispatches"
+         % ((t1 - t0) / 1e6, idle / 1e6, two / 1e6, len(rows))]
+for k, v in sorted(busy.items(), key=lambda kv: -kv[1]):
+    lines.append("%-40s %9.2f ms in %d dispatches" % (k.split("::")[-1][:40], v / 1e6, sum(1 for r in rows if r[2] == k)))
+tq = [(a, b) for a, b, k in rows if "k_trace_queue" in k]
+lines.append("traversal launches, ms: " + " ".join("%.2f" % ((b - a) / 1e6) for a, b in tq))
+open(os.path.join(out, "mesh_render_timeline.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+print(open(os.path.join(out, "render.txt")).read())
+PY
