@@ -192,9 +192,26 @@ int rtr_device_count(int *n);
  */
 int rtr_self_test(int device, uint64_t *mismatches);
 
-/* Uploads the scene to `device` (copies everything; the desc may be freed). */
+/* Uploads the scene to `device` (copies everything; the desc may be freed).  The tree is
+ * checked, renumbered in depth-first order and laid out in records by kernels on the device
+ * (BVH::selfBuildBVH's result, src/BVH.cpp:19-64, is taken as given: its topology and
+ * bounds are the caller's). */
 int rtr_scene_create(const rtr_scene_desc *desc, int device, rtr_scene **out);
 void rtr_scene_destroy(rtr_scene *scene);
+
+/*
+ * The tree as the kernels read it, copied back (for checks and tools).  Nodes are numbered in
+ * depth-first pre-order, left child first (the order BVH::intersect, src/BVH.cpp:66-80,
+ * visits them).  nodes8: 8 floats per node {bmin.xyz, bits(skip), bmax.xyz, bits(leaf)} with
+ * skip = first node after the subtree and leaf = -1 or (prim kind << 30) | row; parent: one
+ * index per node (-1 for the root); leaves16: 16 floats per leaf in depth-first leaf order
+ * (triangle {p0, n.x}{p1-p0, n.y}{p2-p0, n.z}{-, -, bits(node), bits(leaf)}; sphere
+ * {c, r}{r*r, T, bits(sphere number), -}{-}{-, -, bits(node), bits(leaf)}); flags2:
+ * {all box planes inside the division-free test's range, all boxes contain their
+ * children's}.  Call with null arrays to get the counts.  Any output may be NULL.
+ */
+int rtr_scene_read_tree(rtr_scene *scene, int32_t *n_nodes, int32_t *n_leaves, float *nodes8,
+                        int32_t *parent, float *leaves16, int32_t *flags2);
 
 /*
  * Closest hit for a batch of rays: Scene::intersect (include/Scene.h:46) ->

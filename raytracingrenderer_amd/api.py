@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "rtr_sample_light", "rtr_stream_uniform", "rtr_render_pt", "rtr_render_pt_device",
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
     "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
-    "rtr_render_pt_multi_device", "rtr_trace_count_work", "rtr_self_test",
+    "rtr_render_pt_multi_device", "rtr_trace_count_work", "rtr_self_test", "rtr_scene_read_tree",
 ]
 
 _hip = None
@@ -308,6 +308,14 @@ class HostScene:
         self.L.rtrh_set_device(self.h, index)
         self._dev = None
 
+    def flatten_for_upload(self):
+        """Scene::flatten of the host mirror (cached there): the arrays rtr_scene_create takes."""
+        d = self.L.rtrh_scene_desc
+        d.restype = C.c_void_p
+        d.argtypes = [C.c_void_p]
+        if not d(self.h):
+            self._herr("scene desc")
+
     def device_scene(self):
         if self._dev is None:
             p = self.L.rtrh_device_scene(self.h)
@@ -328,6 +336,21 @@ class HostScene:
         _check(hip_lib().rtr_trace_closest(self.device_scene(), _f(org), _f(dirs), n, _i(prim),
                                            _f(t), _f(pos), _f(nrm)), "rtr_trace_closest")
         return prim, t, pos, nrm
+
+    def read_tree(self):
+        """rtr_scene_read_tree: (nodes[N,8] as float32, parent[N], leaves[L,16], (fast, nested))."""
+        L = hip_lib()
+        L.rtr_scene_read_tree.argtypes = [C.c_void_p, _ip, _ip, _fp, _ip, _fp, _ip]
+        n, nl = C.c_int32(0), C.c_int32(0)
+        _check(L.rtr_scene_read_tree(self.device_scene(), C.byref(n), C.byref(nl), None, None, None, None),
+               "rtr_scene_read_tree")
+        nodes = np.zeros((n.value, 8), f32)
+        parent = np.zeros(n.value, np.int32)
+        leaves = np.zeros((nl.value, 16), f32)
+        flags = np.zeros(2, np.int32)
+        _check(L.rtr_scene_read_tree(self.device_scene(), None, None, _f(nodes), _i(parent), _f(leaves),
+                                     _i(flags)), "rtr_scene_read_tree")
+        return nodes, parent, leaves, (int(flags[0]), int(flags[1]))
 
     def intersect_device(self, d_org, d_dir, n, d_prim, d_t, d_pos=None, d_nrm=None, stream=None):
         """rtr_trace_closest_device: device addresses as ints; enqueues, does not wait."""

