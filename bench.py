@@ -200,6 +200,11 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="with one rank under torch.distributed.run: still initialise the process group "
+                         "and run barrier, gather and reductions (the N>1 code path on one GPU)")
+    ap.add_argument("--dump-image", default="",
+                    help="rank 0 saves the last step's whole image (W*H x 3 float32, .npy) here")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other measurement inputs reported after the headline line's timing")
     ap.add_argument("--pool", type=int, default=0, help="path pool size (0 = library default)")
@@ -226,7 +231,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.rehearse_gather
+    if collective:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -240,11 +246,14 @@ def main():
 
     from raytracingrenderer_amd.distributed import ColumnGather, local_buffer
     local = local_buffer(torch, W, H, world, tile, dev)
-    gather = ColumnGather(torch, dist, W, H, rank, world, tile, dev, dst=0) if world > 1 else None
+    gather = (ColumnGather(torch, dist, W, H, rank, world, tile, dev, dst=0, always_collective=True)
+              if collective else None)
 
     agg = {"rays": 0, "vertices": 0, "ms_trace": 0.0, "ms_logic": 0.0, "ms_other": 0.0,
            "ms_fused": 0.0, "trace_launches": 0, "fused_launches": 0, "iterations": 0,
            "samples": 0, "mode": 0}
+
+    last = {"image": None}
 
     def step(record):
         st = scene.render_device(W, H, spp, local.data_ptr(), seed=args.seed, part_index=rank,
@@ -252,7 +261,7 @@ def main():
                                  pool_size=args.pool, chunk_spp=args.chunk, mode=args.mode,
                                  streams=args.streams)
         if gather is not None:
-            gather(local)  # one RCCL gather + column re-ordering on rank 0
+            last["image"] = gather(local)  # one RCCL gather + column re-ordering on rank 0
         if record:
             agg["rays"] += st.rays
             agg["vertices"] += st.vertices
@@ -269,7 +278,7 @@ def main():
         return st
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,7 +292,7 @@ def main():
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(agg["rays"]), float(agg["vertices"])], dtype=torch.float64,
                      device=dev)
-    if world > 1:
+    if collective:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -293,6 +302,9 @@ def main():
     else:
         rays_total, vert_total = float(t[1]), float(t[2])
 
+    if rank == 0 and args.dump_image:
+        img = last["image"] if last["image"] is not None else local[: W * H]
+        np.save(args.dump_image, img.reshape(-1, 3).cpu().numpy())
     if rank == 0:
         samples = float(W) * H * spp * args.steps
         value = samples / elapsed / 1e6
@@ -390,7 +402,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0,
                                        "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -139,7 +139,8 @@ typedef struct rtr_render_params {
   float rr_prob;      /* <=0: 0.6f */
   int32_t chunk_spp;  /* samples summed in sequence per partial sum; <=0: chosen by the library
                          (128 partial sums per pixel, fewer for images beyond about 1000 x
-                         1000 pixels).  It fixes the order in which a pixel's samples are
+                         1000 pixels; chosen from width x height, so every partition of an
+                         image gets the value a whole-image render gets).  It fixes the order in which a pixel's samples are
                          added up and therefore the low bits of the image: compare images
                          rendered with the same chunk_spp (rtr_stats.chunk_spp reports it) */
   int32_t pool_size;  /* wavefront mode: concurrent paths; <=0: auto (2^21, or 2^22 for scenes too large for LDS) */

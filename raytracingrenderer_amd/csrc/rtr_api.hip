@@ -456,7 +456,9 @@ int plan_render(const rtr_scene *s, const rtr_camera *cam, const rtr_render_para
     // default: up to 128 partial sums per pixel -- units small enough that the last one a
     // lane works on is a small share of its run, also when the image is split over 8
     // GPUs -- but no more units than the budget (large images get fewer, longer chunks)
-    size_t chunks = a.n_pix > 0 ? unit_budget / (size_t)a.n_pix : 1;
+    // (sized by the whole image, not by this partition: every partition of an image must
+    // sum its samples in the same order as a one-device render of it)
+    size_t chunks = unit_budget / ((size_t)a.W * (size_t)a.H);
     chunks = std::min<size_t>(std::max<size_t>(chunks, 1), 128);
     a.chunk_spp = (int)((prm->spp + chunks - 1) / chunks);
   }

@@ -27,8 +27,9 @@ def local_buffer(torch, W, H, world, tile_cols, device):
 class ColumnGather:
     """Pre-allocated buffers and index tensors for gathering a W x H framebuffer."""
 
-    def __init__(self, torch, dist, W, H, rank, world, tile_cols, device, dst=0):
+    def __init__(self, torch, dist, W, H, rank, world, tile_cols, device, dst=0, always_collective=False):
         self.torch, self.dist = torch, dist
+        self.always_collective = always_collective  # run the gather even with one rank (rehearsal)
         self.W, self.H, self.rank, self.world, self.dst = W, H, rank, world, dst
         self.n_local = len(partition_columns(W, rank, world, tile_cols))
         self.is_dst = rank == dst
@@ -44,7 +45,7 @@ class ColumnGather:
     def __call__(self, local):
         """local: this rank's packed columns (padded).  Returns the (W, H, 3) image on
         ``dst`` (buffer index i*H + j like the reference's), None elsewhere."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             n = self.n_local
             self.full.copy_(local[: n * self.H].view(n, self.H, 3))
             return self.full

@@ -631,7 +631,8 @@ def test_render_2048_square_image(rt, scenes):
     _assert_images_equal(b, a)
     assert (sb.rays, sb.vertices) == (sa.rays, sa.vertices)
     del b
-    c, sc = sg.render_multi(W, H, 64, [0] * 8, seed=2, chunk_spp=sa.chunk_spp)
+    c, sc = sg.render_multi(W, H, 64, [0] * 8, seed=2)  # default chunking: sized by the whole image
+    assert sc.chunk_spp == sa.chunk_spp
     _assert_images_equal(c, a)
     assert sc.rays == sa.rays
     del c
@@ -817,3 +818,29 @@ def test_scene_create_rejects_malformed_trees(rt):
     d = desc(left, right, prim, 1)
     assert lib.rtr_scene_create(C.byref(d), 0, C.byref(out)) == 0, lib.rtr_last_error()
     lib.rtr_scene_destroy(out)
+
+
+def test_bench_multi_rank_code_path_on_one_gpu(rt, scenes, tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL), rehearsed
+    with one rank: process group, barrier, the gather of a device tensor, the column
+    re-ordering and the reductions all run; the gathered image must equal a plain render."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--width", "96", "--height", "64", "--spp", "8", "--no-cpu-baseline", "--no-extras",
+                        "--rehearse-gather", "--dump-image", str(tmp_path / "img.npy")],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    O, so, sg = scenes
+    want, _ = sg.render(96, 64, 8, seed=0)
+    got = np.load(tmp_path / "img.npy").reshape(-1, 3)
+    _assert_images_equal(got, want)
