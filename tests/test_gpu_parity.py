@@ -844,3 +844,47 @@ def test_bench_multi_rank_code_path_on_one_gpu(rt, scenes, tmp_path):
     want, _ = sg.render(96, 64, 8, seed=0)
     got = np.load(tmp_path / "img.npy").reshape(-1, 3)
     _assert_images_equal(got, want)
+
+
+def _tie_scene_spec(with_walls):
+    """Spheres that coincide pairwise (same centre and radius, different materials), so that
+    equal hit distances are the rule and the winner of a tie decides the picture; with walls
+    (20 spheres, 59 nodes) or without (32 spheres: every bit of the per-ray sphere mask)."""
+    spec = default_scene_spec()
+    rng = np.random.default_rng(5)
+    walls = [ob for ob in spec["objects"] if ob[0] == "mesh"] if with_walls else []
+    objs = [("sphere", "light", (256, 256, -256), 20)]
+    n_pairs = 8 if with_walls else 14
+    mats = ["red", "spec", "micro", "green", "blue", "white"]
+    for k in range(n_pairs):
+        c = tuple(float(x) for x in (rng.uniform(60, 450, 3) * np.array([1, 1, -1])))
+        r = float(rng.uniform(20, 60))
+        objs.append(("sphere", mats[k % 6], c, r))
+        objs.append(("sphere", mats[(k + 1) % 6], c, r))
+    # a sphere that touches the back wall (tangent point hit at the wall's distance) and spares
+    objs.append(("sphere", "white", (256, 256, -512 + 40), 40))
+    objs.append(("sphere", "spec", (120, 400, -300), 25))
+    objs.append(("sphere", "micro", (400, 120, -200), 25))
+    spec["objects"] = objs[:1] + walls + objs[1:]
+    return spec
+
+
+@pytest.mark.parametrize("with_walls", [True, False])
+def test_render_with_coinciding_spheres(rt, with_walls):
+    """The fused kernel finishes its sphere tests out of leaf order (marked spheres, lane by
+    lane); the reference's rule for equal distances -- the later leaf wins -- must still
+    hold.  Images and counters in every loop variant against the checker, bit for bit."""
+    O = Oracle()
+    spec = _tie_scene_spec(with_walls)
+    so = O.build_scene(spec)
+    O.set_math(so, portable=True)
+    sg = rt.HostScene.from_spec(spec)
+    org, d = _rays.interior_rays(100000, seed=3)
+    _assert_hits_equal(sg.intersect(org, d), so.intersect(org, d))
+    want, stats = O.render(so, 64, 48, 12, seed=6, chunk_spp=4)
+    for how in MODES:
+        rgb, st = sg.render(64, 48, 12, seed=6, chunk_spp=4, **how)
+        assert st.mode == how["mode"]
+        _assert_images_equal(rgb, want)
+        assert (st.rays, st.vertices) == (stats[1], stats[3])
+    assert want.mean() > 0.001
