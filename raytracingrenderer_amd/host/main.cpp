@@ -1,10 +1,13 @@
 // Command-line equivalent of the reference's driver (src/main.cpp:5-101): builds
 // the same Cornell-box scene through the same API calls and renders it with
 // path tracing on the GPU.
-//   rtr_main [width height spp [output-basename [seed]]]
+//   rtr_main [width height spp [output-basename [seed [devices]]]]
 // writes <output-basename>.ppm in the reference's format (src/Render.cpp:3-21).
+// devices: comma-separated GPU indices, e.g. 0,1,2,3,4,5,6,7 (a GPU may repeat); the image
+// is then rendered as one partition per entry and gathered on the first (RenderOptions::devices).
 #include <cstdlib>
 #include <iostream>
+#include <sstream>
 
 #include "rtr_host.hpp"
 
@@ -14,6 +17,11 @@ int main(int argc, char **argv) {
   unsigned spp = argc > 3 ? (unsigned)atoi(argv[3]) : 1;
   std::string out = argc > 4 ? argv[4] : "test0";
   unsigned seed = argc > 5 ? (unsigned)atoi(argv[5]) : 0;
+  std::vector<int> devices;
+  if (argc > 6) {
+    std::stringstream list(argv[6]);
+    for (std::string item; std::getline(list, item, ',');) devices.push_back(atoi(item.c_str()));
+  }
 
   Material *whiteLightMaterial = new Material(
       MaterialType::DIFFUSE, 8.0f * Vector3f(0.747f + 0.058f, 0.747f + 0.258f, 0.747f) +
@@ -54,6 +62,7 @@ int main(int argc, char **argv) {
 
   Render renderer;
   renderer.options.seed = seed;
+  renderer.options.devices = devices;
   try {
     renderer.render(scene, W, H, spp, out, RenderType::PathTracing);
   } catch (const std::exception &e) {
@@ -62,6 +71,6 @@ int main(int argc, char **argv) {
   }
   const rtr_stats &st = renderer.getStats();
   std::cout << "samples " << st.samples << "  rays " << st.rays << "  " << st.ms_total << " ms  "
-            << (st.samples / st.ms_total / 1e3) << " Msamples/s\n";
+            << (st.samples / st.ms_total / 1e3) << " Msamples/s on " << st.n_devices << " device(s)\n";
   return 0;
 }
