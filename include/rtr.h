@@ -311,8 +311,8 @@ int rtr_stream_uniform(rtr_scene *scene, uint32_t seed, const uint32_t *pixel,
 
 /*
  * Render::renderPathTracing without the file write: the per-pixel sample loop
- * (src/Render.cpp:651-665) over Render::pathTracing (src/Render.cpp:77-130) as
- * a wavefront path tracer.  rgb_out: n_columns*height*3 floats, pixel (i,j) of
+ * (src/Render.cpp:651-665) over Render::pathTracing (src/Render.cpp:77-130), by
+ * the fused kernel or the wavefront loop (rtr_render_params.mode).  rgb_out: n_columns*height*3 floats, pixel (i,j) of
  * the rendered columns at ((local column)*height + j)*3, i.e. the reference's
  * buffer index i*height+j when nothing is partitioned.  stats may be NULL.
  */
