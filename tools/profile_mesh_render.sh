@@ -9,9 +9,22 @@ OUT=$R/gpurun_out/prof_mesh_render_${1:-r02}
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o mesh -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > $OUT/render.txt 2> $OUT/ktrace.log || { tail -5 $OUT/ktrace.log; exit 1; }
+timeout -s KILL 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > /dev/null 2> $OUT/pmc_fetch.log || { tail -5 $OUT/pmc_fetch.log; exit 1; }
+timeout -s KILL 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > /dev/null 2> $OUT/pmc_write.log || { tail -5 $OUT/pmc_write.log; exit 1; }
 python3 - <<PY
-import csv, glob, os, collections
+import csv, glob, os, collections, json
 out = "$OUT"
+# memory-side traffic per kernel over the whole program (warm-up render included):
+# FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes
+tr = collections.defaultdict(lambda: {"read_bytes": 0.0, "write_bytes": 0.0, "dispatches": 0})
+for d, key, scale in (("pmc_fetch", "read_bytes", 2048.0), ("pmc_write", "write_bytes", 1024.0)):
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("::")[-1]
+            tr[k][key] += float(r["Counter_Value"]) * scale
+            if d == "pmc_fetch": tr[k]["dispatches"] += 1
+json.dump(tr, open(os.path.join(out, "mesh_render_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in tr.items() if v["read_bytes"] + v["write_bytes"] > 1e8}, indent=1))
 for f in glob.glob(os.path.join(out, "ktrace", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(out, "mesh_render_kernel_stats.csv"), "w").write(open(f).read())
     print(open(f).read())
