@@ -68,7 +68,11 @@ int main() {
   float t[8];
   t[0] = run<0>(d, iters); t[1] = run<1>(d, iters); t[2] = run<2>(d, iters); t[3] = run<3>(d, iters);
   t[4] = run<4>(d, iters); t[5] = run<5>(d, iters); t[6] = run<6>(d, iters); t[7] = run<7>(d, iters);
-  for (int i = 0; i < 8; i++) printf("%-28s %8.3f ms  (%.2f x fma)\n", names[i], t[i], t[i] / t[0]);
+  // 1024 blocks x 4 waves over 1024 SIMDs: 4 waves per SIMD, each issuing iters x 8 (x 4 packed) instructions
+  const int per_it[] = {8, 8, 8, 8, 8, 4, 8, 8};
+  for (int i = 0; i < 8; i++)
+    printf("%-28s %8.3f ms  (%.2f x fma)  %.2f ns per wave-instruction and SIMD\n", names[i], t[i], t[i] / t[0],
+           t[i] * 1e6 / (4.0 * iters * per_it[i]));
   for (int blocks : {256, 512, 1024, 2048}) {
     float a = run<0>(d, iters, blocks), b = run<5>(d, iters, blocks);
     printf("blocks %4d (%d waves/SIMD): fma x8 %.3f ms, pk_fma x4 %.3f ms\n", blocks, blocks / 256, a, b);
