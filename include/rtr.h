@@ -15,6 +15,9 @@
  * last failure on the calling thread.  Unless a parameter is documented as a
  * device pointer, pointers are host memory owned by the caller, read or written
  * only during the call.  A handle may be used from one thread at a time.
+ * All scenes on one device launch on the same two streams, which the library
+ * makes at the first rtr_scene_create on that device and keeps: work of
+ * different scenes on one device runs in the order it was submitted.
  */
 #ifndef RTR_H
 #define RTR_H
