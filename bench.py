@@ -262,6 +262,9 @@ def main():
                                  streams=args.streams)
         if gather is not None:
             last["image"] = gather(local)  # one RCCL gather + column re-ordering on rank 0
+            # the gather reads `local` on torch's stream, the next render writes it on the
+            # library's: wait for the gather before going on
+            torch.cuda.current_stream(dev).synchronize()
         if record:
             agg["rays"] += st.rays
             agg["vertices"] += st.vertices
