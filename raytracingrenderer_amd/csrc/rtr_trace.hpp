@@ -1318,31 +1318,23 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
     out.node_a = ba.k >= 0 ? la.x : -1;
     out.node_b = bb.k >= 0 ? lb.x : -1;
   }
-  // both winners' boxes: the leaf's own box, or leaf to root (see trace_all)
-  const bool fast = sc.fast_planes != 0 && fast_ray(o, dn_a) && fast_ray(o, dn_b);
-  const bool leaf_only = fast && sc.nested_boxes != 0;
-  const V3 inv_a = mk(1.0f / dn_a.x, 1.0f / dn_a.y, 1.0f / dn_a.z);
-  const V3 inv_b = mk(1.0f / dn_b.x, 1.0f / dn_b.y, 1.0f / dn_b.z);
-  bool ok_a = true, ok_b = true;
-  int na = out.node_a, nb = out.node_b;
-  while (na >= 0 || nb >= 0) {
-    // a finished chain re-tests the root: harmless, and keeps the loop body straight
-    const int ia = na >= 0 ? na : 0, ib = nb >= 0 ? nb : 0;
-    const float4 lo_a = lds.nodes[2 * ia], hi_a = lds.nodes[2 * ia + 1];
-    const float4 lo_b = lds.nodes[2 * ib], hi_b = lds.nodes[2 * ib + 1];
-    bool pa, pb;
-    if (fast) {
-      pa = slab_fast(lo_a, hi_a, o, dn_a, inv_a);
-      pb = slab_fast(lo_b, hi_b, o, dn_b, inv_b);
-    } else {
-      pa = slab(lo_a, hi_a, o, dn_a);
-      pb = slab(lo_b, hi_b, o, dn_b);
+  // both winners' boxes: the leaf's own box, or leaf to root (see trace_all); one ray after
+  // the other, so that only one test's quotients are in registers at a time
+  const bool leaf_only = sc.fast_planes != 0 && sc.nested_boxes != 0;
+  auto chain_ok = [&](int node, V3 d) {
+    const bool fast = sc.fast_planes != 0 && fast_ray(o, d);
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool ok = true;
+    while (node >= 0) {
+      const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
+      const bool pass = fast ? slab_fast(lo, hi, o, d, inv) : slab(lo, hi, o, d);
+      ok = ok && pass;
+      node = (leaf_only && fast) ? -1 : lds.parent[node];
     }
-    ok_a = ok_a && (pa || na < 0);
-    ok_b = ok_b && (pb || nb < 0);
-    na = (na >= 0 && !leaf_only) ? lds.parent[ia] : -1;
-    nb = (nb >= 0 && !leaf_only) ? lds.parent[ib] : -1;
-  }
+    return ok;
+  };
+  const bool ok_a = chain_ok(out.node_a, dn_a);
+  const bool ok_b = chain_ok(out.node_b, dn_b);
   unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
   unsigned long long need_b = __ballot(valid_b && (bb.nan_seen || !ok_b));
   if (need_a | need_b) {
