@@ -936,6 +936,14 @@ RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const Hit
 struct UnitState {
   float fpos[3][kBlock], fN[3][kBlock], fwi[3][kBlock], acc[3][kBlock];
   uint32_t fmat[kBlock], out[kBlock], k_end[kBlock];  // out: index of the unit's partial sum
+  uint32_t n_vertices[kBlock], n_rays[kBlock];          // the lane's statistics
+};
+// Radiance of the lane's current path so far: in LDS where the workgroup has room for it (the
+// flavour with staged geometry: three registers fewer make its fourth wave spill-free), in
+// registers in the tree-walking flavour, whose per-wave rings need the space.
+template <bool kInLds>
+struct UnitStateOf : UnitState {
+  float Lp[kInLds ? 3 : 1][kInLds ? kBlock : 1];
 };
 
 // Kernel arguments that are only needed when a lane takes a new work unit or finishes one
@@ -990,7 +998,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
   __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
   __shared__ LdsShade lsh;
-  __shared__ UnitState us;
+  __shared__ UnitStateOf<kLds> us;
   const int tid = threadIdx.x;
   if (kLds) {
     stage_scene(sc, lds, tid, kBlock);
@@ -1027,7 +1035,8 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
   V3 pos = mk(0, 0, 0), N = pos, wi = pos, beta = pos, Lp = pos;
   uint32_t mat = 0, depth = 0;
   bool live = false;
-  uint32_t n_vertices = 0, n_rays = 0;
+  us.n_vertices[tid] = 0;
+  us.n_rays[tid] = 0;
 
   for (;;) {
     if (!live) {
@@ -1082,7 +1091,8 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         wi = mk(us.fwi[0][tid], us.fwi[1][tid], us.fwi[2][tid]);
         mat = us.fmat[tid];
         beta = mk(1, 1, 1);
-        Lp = mk(0, 0, 0);
+        if constexpr (kLds) { us.Lp[0][tid] = 0; us.Lp[1][tid] = 0; us.Lp[2][tid] = 0; }
+        else Lp = mk(0, 0, 0);
         depth = 0;
         live = true;
       }
@@ -1096,8 +1106,8 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if (live) {
       if (kLds) shade_vertex(a, LdsTables{lds, lsh, L.n_lights, L.total_area}, pos, N, wi, beta, mat, gpix, k, depth, e);
       else shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
-      n_vertices++;
-      n_rays += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
+      us.n_vertices[tid] += 1u;
+      us.n_rays[tid] += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
     }
     if (!e.has_shadow) { e.l = mk(1, 1, 1); e.ln = unit(e.l); }
     if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = unit(e.w1); }
@@ -1124,7 +1134,14 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         float dl = length(hp - e.light_pos);
         if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
           V3 term = e.weight / (hs.t * hs.t) / e.light_pdf;
-          Lp = Lp + beta * term;
+          const V3 add = beta * term;
+          if constexpr (kLds) {
+            us.Lp[0][tid] = us.Lp[0][tid] + add.x;
+            us.Lp[1][tid] = us.Lp[1][tid] + add.y;
+            us.Lp[2][tid] = us.Lp[2][tid] + add.z;
+          } else {
+            Lp = Lp + add;
+          }
         }
       }
       // extension result: src/Render.cpp:117-125
@@ -1147,16 +1164,22 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       }
       if (!cont) {
         // color = color + pathTracing(...), src/Render.cpp:659
-        us.acc[0][tid] = us.acc[0][tid] + Lp.x;
-        us.acc[1][tid] = us.acc[1][tid] + Lp.y;
-        us.acc[2][tid] = us.acc[2][tid] + Lp.z;
+        if constexpr (kLds) {
+          us.acc[0][tid] = us.acc[0][tid] + us.Lp[0][tid];
+          us.acc[1][tid] = us.acc[1][tid] + us.Lp[1][tid];
+          us.acc[2][tid] = us.acc[2][tid] + us.Lp[2][tid];
+        } else {
+          us.acc[0][tid] = us.acc[0][tid] + Lp.x;
+          us.acc[1][tid] = us.acc[1][tid] + Lp.y;
+          us.acc[2][tid] = us.acc[2][tid] + Lp.z;
+        }
         k++;
         live = false;
       }
     }
   }
   // statistics: one atomic pair per wave
-  unsigned long long nv = n_vertices, nr = n_rays;
+  unsigned long long nv = us.n_vertices[tid], nr = us.n_rays[tid];
   for (int off = 32; off > 0; off >>= 1) {
     nv += __shfl_down(nv, off);
     nr += __shfl_down(nr, off);

@@ -1323,7 +1323,10 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
   const bool leaf_only = sc.fast_planes != 0 && sc.nested_boxes != 0;
   auto chain_ok = [&](int node, V3 d) {
     const bool fast = sc.fast_planes != 0 && fast_ray(o, d);
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // RN(1/d): a fast ray's direction components are within reciprocal_fast's range
+    V3 inv;
+    if (__ballot(!fast) == 0) inv = mk(reciprocal_fast(d.x), reciprocal_fast(d.y), reciprocal_fast(d.z));
+    else inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     bool ok = true;
     while (node >= 0) {
       const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
