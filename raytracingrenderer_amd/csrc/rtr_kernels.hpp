@@ -936,14 +936,15 @@ RTR_DEV void hit_point_any(const DeviceScene &sc, const LdsScene &lds, const Hit
 struct UnitState {
   float fpos[3][kBlock], fN[3][kBlock], fwi[3][kBlock], acc[3][kBlock];
   uint32_t fmat[kBlock], out[kBlock], k_end[kBlock];  // out: index of the unit's partial sum
-  uint32_t n_vertices[kBlock], n_rays[kBlock];          // the lane's statistics
 };
-// Radiance of the lane's current path so far: in LDS where the workgroup has room for it (the
-// flavour with staged geometry: three registers fewer make its fourth wave spill-free), in
-// registers in the tree-walking flavour, whose per-wave rings need the space.
+// Radiance of the lane's current path so far and the lane's statistics: in LDS where the
+// workgroup has room for them (the flavour with staged geometry: five registers fewer make its
+// fourth wave spill-free), in registers in the tree-walking flavour, whose per-wave rings
+// need the space.
 template <bool kInLds>
 struct UnitStateOf : UnitState {
   float Lp[kInLds ? 3 : 1][kInLds ? kBlock : 1];
+  uint32_t n_vertices[kInLds ? kBlock : 1], n_rays[kInLds ? kBlock : 1];
 };
 
 // Kernel arguments that are only needed when a lane takes a new work unit or finishes one
@@ -1035,8 +1036,11 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
   V3 pos = mk(0, 0, 0), N = pos, wi = pos, beta = pos, Lp = pos;
   uint32_t mat = 0, depth = 0;
   bool live = false;
-  us.n_vertices[tid] = 0;
-  us.n_rays[tid] = 0;
+  uint32_t n_vertices = 0, n_rays = 0;
+  if constexpr (kLds) {
+    us.n_vertices[tid] = 0;
+    us.n_rays[tid] = 0;
+  }
 
   for (;;) {
     if (!live) {
@@ -1106,8 +1110,14 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if (live) {
       if (kLds) shade_vertex(a, LdsTables{lds, lsh, L.n_lights, L.total_area}, pos, N, wi, beta, mat, gpix, k, depth, e);
       else shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
-      us.n_vertices[tid] += 1u;
-      us.n_rays[tid] += (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
+      const uint32_t new_rays = (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
+      if constexpr (kLds) {
+        us.n_vertices[tid] += 1u;
+        us.n_rays[tid] += new_rays;
+      } else {
+        n_vertices++;
+        n_rays += new_rays;
+      }
     }
     if (!e.has_shadow) { e.l = mk(1, 1, 1); e.ln = unit(e.l); }
     if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = unit(e.w1); }
@@ -1179,7 +1189,11 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     }
   }
   // statistics: one atomic pair per wave
-  unsigned long long nv = us.n_vertices[tid], nr = us.n_rays[tid];
+  if constexpr (kLds) {
+    n_vertices = us.n_vertices[tid];
+    n_rays = us.n_rays[tid];
+  }
+  unsigned long long nv = n_vertices, nr = n_rays;
   for (int off = 32; off > 0; off >>= 1) {
     nv += __shfl_down(nv, off);
     nr += __shfl_down(nr, off);
