@@ -350,8 +350,9 @@ def main():
                             "of the FMA-counted peak is reachable"}
         if fused:
             # nothing streams through HBM in this kernel by design (path state, rays and hits
-            # stay in registers): what it should move is its partial sums and the pixel cache
-            roofline["algorithmic_hbm_bytes_per_launch"] = 16.0 * W * H * -(-spp // chunk_used) + 52.0 * W * H
+            # stay in registers): per work unit (pixel x chunk of samples) it reads the pixel's
+            # first vertex (three 16-byte records and its list entry) and writes one partial sum
+            roofline["algorithmic_hbm_bytes_per_launch"] = (16.0 + 52.0) * W * H * -(-spp // chunk_used)
         else:
             gbs = BYTES_PER_QUERY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",

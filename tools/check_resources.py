@@ -6,7 +6,9 @@ Reads the compiler's resource-usage remarks (hipcc -Rpass-analysis=kernel-resour
 scalar registers than the ceilings below.  Scalar spills go into lanes of a vector register
 on gfx950; one build of this kernel with 45 of them lost radiance at depth >= 1 (same rays
 traced, wrong image), so growth in that number is treated as a defect, not as noise.
-Vector spills (scratch memory) only cost time and are reported.
+Vector spills go to scratch memory: the kernel with 59 of them moved 160 GB per 784 x 784 x
+1024 render where its work units name 5 GB, so the flavour that renders the headline scene
+is held at none; the tree-walking flavour's are reported and capped.
 
 usage: check_resources.py <file with the remarks> [--json]
 """
@@ -14,10 +16,10 @@ import json
 import re
 import sys
 
-# kernel-name fragment -> (most SGPR spills allowed, least waves per SIMD)
+# kernel-name fragment -> (most SGPR spills allowed, least waves per SIMD, most VGPR spills allowed)
 GATES = {
-    "k_render_fusedILb1E": (12, 4),   # scene staged in LDS (the Cornell box)
-    "k_render_fusedILb0E": (16, 4),   # tree walked in memory
+    "k_render_fusedILb1E": (12, 4, 0),    # scene staged in LDS (the Cornell box)
+    "k_render_fusedILb0E": (16, 4, 32),   # tree walked in memory
 }
 
 
@@ -37,7 +39,7 @@ def parse(text):
 def main():
     usage = parse(open(sys.argv[1]).read())
     report, bad = {}, []
-    for frag, (max_sgpr_spill, min_waves) in GATES.items():
+    for frag, (max_sgpr_spill, min_waves, max_vgpr_spill) in GATES.items():
         names = [n for n in usage if frag in n]
         if len(names) != 1:
             bad.append("%s: %d kernels match" % (frag, len(names)))
@@ -49,6 +51,8 @@ def main():
         report[frag] = rec
         if not (0 <= rec["sgpr_spill"] <= max_sgpr_spill):
             bad.append("%s: %d SGPR spills (ceiling %d)" % (frag, rec["sgpr_spill"], max_sgpr_spill))
+        if rec["vgpr_spill"] > max_vgpr_spill:
+            bad.append("%s: %d VGPR spills (ceiling %d)" % (frag, rec["vgpr_spill"], max_vgpr_spill))
         if rec["waves_per_simd"] < min_waves:
             bad.append("%s: %d waves per SIMD (at least %d)" % (frag, rec["waves_per_simd"], min_waves))
     print(json.dumps(report, indent=1) if "--json" in sys.argv else
