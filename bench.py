@@ -348,6 +348,22 @@ def main():
                     "note": "fp32 VALU-issue bound (the 37-node scene sits in LDS and the "
                             "scalar cache); parity forbids FMA contraction, so at most half "
                             "of the FMA-counted peak is reachable"}
+        if fused and traffic is not None:
+            # Issue rate: wave-level vector instructions of one launch (SQ_INSTS_VALU of a separate
+            # counter pass, profiles/) over the 1024 SIMDs and the launch's duration, against what
+            # tools/ubench/valu_rates.hip measures for independent v_fma_f32 / v_mul_f32 at four
+            # waves per SIMD (1.35 ns; a packed instruction takes 2.74 ns, v_rcp_f32 4.4 ns)
+            try:
+                n_inst = json.load(open(tpath)).get(kernel + "_valu_instructions_per_launch")
+            except Exception:
+                n_inst = None
+            if n_inst and avg_ms > 0:
+                scale = float(W) * H * spp / (784.0 * 784.0 * 1024.0)  # counted on the default workload
+                ns = avg_ms * 1e6 / (n_inst * scale / 1024.0)
+                roofline["vector_issue"] = {"ns_per_wave_instruction_and_simd": ns,
+                                            "measured_floor_ns_plain_fp32": 1.35,
+                                            "frac_of_measured_issue_rate": 1.35 / ns,
+                                            "valu_instructions_per_launch": n_inst * scale}
         if fused:
             # nothing streams through HBM in this kernel by design (path state, rays and hits
             # stay in registers): per work unit (pixel x chunk of samples) it reads the pixel's

@@ -29,6 +29,9 @@ for k in res["fetch"]:
     f = res["fetch"][k].get("FETCH_SIZE", 0.0); w = res["write"].get(k, {}).get("WRITE_SIZE", 0.0)
     # both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes
     traffic[k.split("::")[-1].split("<")[0] + "_hbm_bytes_per_launch"] = 2.0 * f * 1024 + w * 1024
+for k, v in res["sq"].items():
+    if "SQ_INSTS_VALU" in v:  # wave-level vector instructions of one launch
+        traffic[k.split("::")[-1].split("<")[0] + "_valu_instructions_per_launch"] = v["SQ_INSTS_VALU"]
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(out, "ktrace", "**", "*kernel_stats.csv"), recursive=True):
     print(open(f).read())
