@@ -218,6 +218,20 @@ int rtr_scene_read_tree(rtr_scene *scene, int32_t *n_nodes, int32_t *n_leaves, f
                         int32_t *parent, float *leaves16, int32_t *flags2);
 
 /*
+ * For scenes small enough for the fused kernel's staged geometry (n_records is 0 otherwise),
+ * the record table its pass over the leaves reads, copied back (for checks and tools): the
+ * leaf records of rtr_scene_read_tree in the same order, except that of two neighbouring
+ * triangle leaves that split a parallelogram (p0 p1 p2 / p3 p2 p1: e1' = -e1, e2' = -e2
+ * exactly, equal normals -- every wall of the scene of src/main.cpp:26-39) only the first
+ * has a record, whose 13th word holds 1 + the pair's number; seconds12 holds the second
+ * triangles' {p0, -}{e1, -}{e2, -} by pair.  The kernel takes the direction-dependent terms
+ * of the second triangle's test (src/Trangle.cpp:10-12) over from the first.  No counterpart
+ * in the reference.  Call with null arrays to get the counts.  Any output may be NULL.
+ */
+int rtr_scene_read_pairs(rtr_scene *scene, int32_t *n_records, int32_t *n_pairs, float *records16,
+                         float *seconds12);
+
+/*
  * Closest hit for a batch of rays: Scene::intersect (include/Scene.h:46) ->
  * BVH::intersect (src/BVH.cpp:66-80) -> Bound3::intersect (src/Bound3.cpp:3-22),
  * Trangle::intersect (src/Trangle.cpp:3-28), Sphere::intersect

@@ -64,6 +64,7 @@ ABI_SYMBOLS = [
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
     "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
     "rtr_render_pt_multi_device", "rtr_trace_count_work", "rtr_self_test", "rtr_scene_read_tree",
+    "rtr_scene_read_pairs",
 ]
 
 _hip = None
@@ -351,6 +352,19 @@ class HostScene:
         _check(L.rtr_scene_read_tree(self.device_scene(), None, None, _f(nodes), _i(parent), _f(leaves),
                                      _i(flags)), "rtr_scene_read_tree")
         return nodes, parent, leaves, (int(flags[0]), int(flags[1]))
+
+    def read_pairs(self):
+        """rtr_scene_read_pairs: (records[R,16], seconds[P,12]) of the fused kernel's leaf pass."""
+        L = hip_lib()
+        L.rtr_scene_read_pairs.argtypes = [C.c_void_p, _ip, _ip, _fp, _fp]
+        n, npairs = C.c_int32(0), C.c_int32(0)
+        _check(L.rtr_scene_read_pairs(self.device_scene(), C.byref(n), C.byref(npairs), None, None),
+               "rtr_scene_read_pairs")
+        records = np.zeros((n.value, 16), f32)
+        seconds = np.zeros((npairs.value, 12), f32)
+        _check(L.rtr_scene_read_pairs(self.device_scene(), None, None, _f(records), _f(seconds)),
+               "rtr_scene_read_pairs")
+        return records, seconds
 
     def intersect_device(self, d_org, d_dir, n, d_prim, d_t, d_pos=None, d_nrm=None, stream=None):
         """rtr_trace_closest_device: device addresses as ints; enqueues, does not wait."""

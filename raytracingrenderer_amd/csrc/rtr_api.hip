@@ -85,7 +85,7 @@ struct rtr_scene {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second half of the path pool runs here, overlapping the first
-  DevBuf<float4> nodes, tris, sphs, lights, leaves;
+  DevBuf<float4> nodes, tris, sphs, lights, leaves, items, pair_second;
   DevBuf<int32_t> parent, node_info;
   DevBuf<float4> light_le;
   int n_light_tris = 0;
@@ -301,8 +301,12 @@ int build_scene_arrays(rtr_scene *s, const rtr_scene_desc *d, bool info_fits, Bu
   if (N) {
     hipLaunchKernelGGL(k_build_place, grid(N), dim3(kBuildBlock), 0, st, in, tmp, out, dflags.ptr);
     hipLaunchKernelGGL(k_build_parent, grid(N), dim3(kBuildBlock), 0, st, in, tmp, out, dflags.ptr);
-    if (L <= (size_t)kLdsLeaves)
-      hipLaunchKernelGGL(k_build_sphere_numbers, dim3(1), dim3(64), 0, st, s->leaves.ptr, (int)L);
+    if (L <= (size_t)kLdsLeaves) {
+      HIP_TRY(s->items.reserve(4 * (L + 1)));
+      HIP_TRY(s->pair_second.reserve(3 * (L / 2 + 1)));
+      hipLaunchKernelGGL(k_build_items, dim3(1), dim3(64), 0, st, s->leaves.ptr, (int)L, s->items.ptr,
+                         s->pair_second.ptr, dflags.ptr);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&flags, dflags.ptr, sizeof(flags), hipMemcpyDeviceToHost, st));
   }
@@ -794,6 +798,10 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.parent = s->parent.ptr;
   s->ds.n_leaves = n_leaves;
   s->ds.nested_boxes = nested_boxes ? 1 : 0;
+  s->ds.items = s->items.ptr;
+  s->ds.pair_second = s->pair_second.ptr;
+  s->ds.n_items = (int32_t)flags.n_items;
+  s->ds.n_pairs = (int32_t)flags.n_pairs;
   s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs &&
                     info_fits && fits_lds_shade(d->n_materials, d->n_lights, (int)light_tris.size());
   s->n_light_tris = (int)light_tris.size();
@@ -828,13 +836,25 @@ int rtr_scene_read_tree(rtr_scene *s, int32_t *n_nodes, int32_t *n_leaves, float
   return RTR_OK;
 }
 
+int rtr_scene_read_pairs(rtr_scene *s, int32_t *n_records, int32_t *n_pairs, float *records16,
+                         float *seconds12) {
+  if (!s) return fail(RTR_ERR_INVALID, "scene is null");
+  if (n_records) *n_records = s->ds.n_items;
+  if (n_pairs) *n_pairs = s->ds.n_pairs;
+  DeviceGuard guard(s->device);
+  const size_t R = (size_t)s->ds.n_items, P = (size_t)s->ds.n_pairs;
+  if (records16 && R) HIP_TRY(hipMemcpy(records16, s->items.ptr, R * 64, hipMemcpyDeviceToHost));
+  if (seconds12 && P) HIP_TRY(hipMemcpy(seconds12, s->pair_second.ptr, P * 48, hipMemcpyDeviceToHost));
+  return RTR_OK;
+}
+
 void rtr_scene_destroy(rtr_scene *s) {
   if (!s) return;
   DeviceGuard guard(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);  // the device's streams outlive the scene
   if (s->stream2) (void)hipStreamSynchronize(s->stream2);
   s->nodes.release(); s->tris.release(); s->sphs.release(); s->lights.release();
-  s->leaves.release(); s->parent.release(); s->node_info.release(); s->light_le.release();
+  s->leaves.release(); s->items.release(); s->pair_second.release(); s->parent.release(); s->node_info.release(); s->light_le.release();
   s->tri_prim.release(); s->sph_prim.release(); s->prim_kind_row.release();
   s->prim_material.release(); s->light_tris.release(); s->tri_area.release(); s->mats.release();
   s->ws.release();

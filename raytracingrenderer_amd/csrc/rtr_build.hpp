@@ -39,7 +39,7 @@ struct BuildFlags {
   uint32_t errors;
   uint32_t slow_planes;  // != 0: some box plane is outside the division-free test's range
   uint32_t not_nested;   // != 0: some box does not contain its child's box
-  uint32_t pad;
+  uint32_t n_items, n_pairs;  // trace_all2's record table (small scenes)
 };
 
 // The description's arrays in device memory (copies, freed after the build).
@@ -243,13 +243,50 @@ k_build_parent(BuildInput in, BuildTemp tmp, BuildOutput out, BuildFlags *flags)
   if (!inside) flags->not_nested = 1u;
 }
 
-// Sphere leaves numbered in leaf order (the bit a ray marks in trace_all2): only scenes small
-// enough for LDS need it, so one thread walks the few leaf records.
-__global__ void k_build_sphere_numbers(float4 *leaves, int n_leaves) {
+// What only scenes small enough for LDS use; one thread walks the few leaf records.
+//  * Sphere leaves are numbered in leaf order (the bit a ray marks in trace_all2).
+//  * The record table of trace_all2: the leaf records again, but of a mirrored pair only the
+//    first, marked with 1 + the pair's number in its first spare word; the second triangle's
+//    {p0, e1, e2} go to pair_second.  Leaves k and k + 1 are a mirrored pair when both are
+//    triangles with e1' = -e1, e2' = -e2 and the same normal -- the two halves of a
+//    parallelogram (p0 p1 p2 / p3 p2 p1).  trace_all2 then takes the second triangle's
+//    direction-dependent terms over from the first; the conditions below are the ones its
+//    argument needs: non-zero components negated bit for bit, zero components +0 in both,
+//    the non-zero components of magnitude in [2^-60, 2^60], normals equal as numbers.
+__device__ inline bool mirrored_component(float a, float b) {
+  const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  if (ua == 0u) return ub == 0u;
+  if (ub != (ua ^ 0x80000000u)) return false;
+  const float m = fabsf(a);
+  return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // false for -0, infinity, NaN
+}
+__global__ void k_build_items(float4 *leaves, int n_leaves, float4 *items, float4 *pair_second,
+                              BuildFlags *flags) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int32_t j = 0;
   for (int k = 0; k < n_leaves; k++)
     if (__float_as_int(leaves[4 * k + 3].w) >> 30) leaves[4 * k + 1].z = __int_as_float(j++);
+  int32_t n = 0, n_pairs = 0;
+  for (int k = 0; k < n_leaves; k++) {
+    const float4 *a = leaves + 4 * k, *b = a + 4;
+    float4 *it = items + 4 * n++;
+    it[0] = a[0]; it[1] = a[1]; it[2] = a[2]; it[3] = a[3];
+    if ((__float_as_int(a[3].w) >> 30) || k + 1 >= n_leaves || (__float_as_int(b[3].w) >> 30)) continue;
+    const bool edges = mirrored_component(a[1].x, b[1].x) && mirrored_component(a[1].y, b[1].y) &&
+                       mirrored_component(a[1].z, b[1].z) && mirrored_component(a[2].x, b[2].x) &&
+                       mirrored_component(a[2].y, b[2].y) && mirrored_component(a[2].z, b[2].z);
+    const bool normals = a[0].w == b[0].w && a[1].w == b[1].w && a[2].w == b[2].w;  // false for NaN
+    if (edges && normals) {
+      pair_second[3 * n_pairs] = b[0];
+      pair_second[3 * n_pairs + 1] = b[1];
+      pair_second[3 * n_pairs + 2] = b[2];
+      it[3].x = __int_as_float(++n_pairs);
+      k++;
+    }
+  }
+  for (int q = 0; q < 4; q++) items[4 * n + q] = make_float4(0, 0, 0, 0);  // read past the end
+  flags->n_items = (uint32_t)n;
+  flags->n_pairs = (uint32_t)n_pairs;
 }
 
 } // namespace rtr

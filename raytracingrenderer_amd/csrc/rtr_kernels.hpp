@@ -957,6 +957,9 @@ struct ColdArgs {
   float4 *partial;
   Counters *fc;
   uint32_t n_pix, chunk_spp, spp;
+  // the record table of trace_all2: read back (wave-uniform) at the start of every pass
+  const float4 *items;
+  int32_t n_items, n_pairs;
 };
 
 // prim id, material and emissive flag of a hit
@@ -1021,6 +1024,9 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     cold.n_pix = (uint32_t)a.n_pix;
     cold.chunk_spp = (uint32_t)a.chunk_spp;
     cold.spp = (uint32_t)a.spp;
+    cold.items = sc.items;
+    cold.n_items = sc.n_items;
+    cold.n_pairs = sc.n_pairs;
   }
   __syncthreads();
   // the number of pixels that need sampling comes straight from the classification
@@ -1127,7 +1133,12 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     if constexpr (kLds) {
 
       // both rays leave the same point: one pass over the leaves for the two of them
-      const HitPair hp = trace_all2(sc, lds, e.has_shadow, e.has_ext, pos, e.l, ln, e.w1, wn, ws.merge);
+      const uint64_t table = (uint64_t)cold.items;
+      const float4 *items = (const float4 *)(((uint64_t)wave_first((uint32_t)(table >> 32)) << 32) |
+                                             wave_first((uint32_t)table));
+      const HitPair hp = trace_all2(sc, items, (int)wave_first((uint32_t)cold.n_items),
+                                    wave_first((uint32_t)cold.n_pairs) != 0u, lds, e.has_shadow, e.has_ext,
+                                    pos, e.l, ln, e.w1, wn, ws.merge);
       hs = hp.a;
       he = hp.b;
       node_e = hp.node_b;

@@ -46,6 +46,11 @@ struct DeviceScene {
   const int32_t *parent;
   int32_t n_leaves;
   int32_t nested_boxes;  // 1: every node's box contains its children's boxes, plane by plane
+  // small scenes only (see trace_all2): the leaf records without the second triangles of
+  // mirrored pairs, and those triangles' {p0, e1, e2} by pair
+  const float4 *items;
+  const float4 *pair_second;
+  int32_t n_items, n_pairs;
 };
 
 // Where traversal reads geometry from.  GlobalGeom gathers from HBM through the
@@ -921,12 +926,15 @@ struct LdsScene {
   // by sphere number j (depth-first order among the sphere leaves): {c, r} and
   // {r*r, T, bits(k), -} of the leaf record (see trace_all)
   float4 sph_leaf[kLdsSphs], sph_aux[kLdsSphs];
+  // by mirrored pair: the second triangle's p0, e1, e2 (see trace_all2)
+  float4 pair_second[3 * (kLdsTris / 2)];
 };
 RTR_DEV void stage_scene(const DeviceScene &sc, LdsScene &s, int tid, int nthreads) {
   for (int k = tid; k < 2 * sc.n_nodes; k += nthreads) s.nodes[k] = sc.nodes[k];
   for (int k = tid; k < 3 * sc.n_tris; k += nthreads) s.tris[k] = sc.tris[k];
   for (int k = tid; k < sc.n_sphs; k += nthreads) s.sphs[k] = sc.sphs[k];
   for (int k = tid; k < sc.n_nodes; k += nthreads) s.parent[k] = sc.parent[k];
+  for (int k = tid; k < 3 * sc.n_pairs; k += nthreads) s.pair_second[k] = sc.pair_second[k];
   for (int k = tid; k < sc.n_leaves; k += nthreads) {
     const float4 r0 = sc.leaves[4 * k], r1 = sc.leaves[4 * k + 1], r3 = sc.leaves[4 * k + 3];
     const int leaf = __float_as_int(r3.w);
@@ -1177,6 +1185,15 @@ struct BestHit {
   }
 };
 
+// x for a zero of either sign, -x otherwise
+RTR_DEV f32x2 negate_nonzero(f32x2 v) {
+  return f32x2{v.x == 0.0f ? v.x : -v.x, v.y == 0.0f ? v.y : -v.y};
+}
+RTR_DEV bool mirror_dir_ok(V3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  return fminf(fminf(ax, ay), az) >= kFastLo && fmaxf(fmaxf(ax, ay), az) <= 2.0f;
+}
+
 // trace_all for two rays that leave the same point, in two phases.
 //
 // 1. One pass over the leaf table (wave-uniform leaf, data in SGPRs, packed arithmetic as
@@ -1197,11 +1214,10 @@ struct HitPair {
   int node_a, node_b;  // the leaves' node indices (-1 for a miss)
 };
 
-RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool valid_a, bool valid_b,
+RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int n_items, bool has_pairs,
+                           const LdsScene &lds, bool valid_a, bool valid_b,
                            V3 o, V3 dir_a, V3 dn_a, V3 dir_b, V3 dn_b, MergeStack &merge) {
   const unsigned lane = threadIdx.x & 63u;
-  const const_leaf *tab = (const const_leaf *)sc.leaves;
-  const int n_leaves = sc.n_leaves;
   const V3x2 dir = pair(dir_a, dir_b), dn = pair(dn_a, dn_b);
   const V3x2 ndir = V3x2{-dir.x, -dir.y, -dir.z};
   const f32x2 qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
@@ -1216,9 +1232,45 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
   const bool a_fast = a_half && qa.x <= 2.0f && qa.y <= 2.0f;
   f32x2 ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
   asm volatile("" : "+v"(ya));  // formed once here, not again in every round of phase 2
-  LeafRecord r = load_leaf(tab, 0);
-  for (int k = 0; k < n_leaves; k++) {
-    const LeafRecord nx = load_leaf(tab, k + 1);
+  // Mirrored pairs.  Two triangles that split a parallelogram (p0 p1 p2 and p3 p2 p1, like every
+  // wall of the reference's scene, src/main.cpp:26-39) have e1' = -e1 and e2' = -e2.  When two
+  // such leaves are neighbours, the negations are exact (zero components +0 in both, the
+  // others of magnitude in [2^-60, 2^60]) and the normals agree, the scene upload leaves the
+  // second one out of the record table, marks the first and keeps the second's own p0, e1, e2
+  // by pair.  Of the second triangle's test,
+  //   s1' = cross(dn, e2'): every product changes sign, so a non-zero component is the first
+  //        triangle's negated and a zero component (both products zero, or equal) is the same
+  //        zero -- provided no product underflows: direction components of magnitude in
+  //        [2^-20, 2];
+  //   se' = dot(s1', e1'): the same non-zero products in the same order (zero products may
+  //        differ in sign, which a non-zero sum does not see): the same bits unless se is zero;
+  //   1 / se' follows, and so does the facing test (normals equal as numbers: `< 0` of the
+  //        sum does not see the sign of a zero term).
+  // Everything else is computed from the second triangle's own data.  A ray outside the two
+  // conditions is marked like one that met a NaN distance and re-traced literally.
+  const const_leaf *items = (const const_leaf *)item_table;
+  if (has_pairs) {
+    ba.nan_seen = !mirror_dir_ok(dn_a);
+    bb.nan_seen = !mirror_dir_ok(dn_b);
+  }
+  auto finish = [&](V3 s, V3 e1, V3 e2, const V3x2 &s1, f32x2 inv, f32x2 facing, int k) {
+    const V3 s2 = cross(s, e1);
+    const float tnum = dot(s2, e2);
+    const f32x2 t = inv * splat(tnum);
+    const f32x2 b1 = inv * dot(s1, splat(s));
+    const f32x2 b2 = inv * dot(splat(s2), dn);
+    const f32x2 w = splat(1.0f) - b1 - b2;
+    const bool hit_a = !(facing.x < 0) &&
+                       !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
+    const bool hit_b = !(facing.y < 0) &&
+                       !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
+    ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
+    bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
+  };
+  LeafRecord r = load_leaf(items, 0);
+  int k = 0;  // the leaf's number in depth-first leaf order
+  for (int i = 0; i < n_items; i++) {
+    const LeafRecord nx = load_leaf(items, i + 1);
     if (r.leaf >> 30) {
       // Sphere::intersect, src/Sphere.cpp:3-15
       const V3 oc = o - mk(r.a0, r.a1, r.a2);
@@ -1236,27 +1288,27 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const LdsScene &lds, bool vali
       const bool behind_b = cc > 0 && b.y > 0 && b.y < 8192.0f && a_half;
       reach_a |= (valid_a && outside && !(delta.x < 0) && !behind_a) ? bit : 0u;
       reach_b |= (valid_b && outside && !(delta.y < 0) && !behind_b) ? bit : 0u;
+      k++;
     } else {
       // Trangle::intersect, src/Trangle.cpp:3-28
       const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
       const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
-      const V3 s = o - p0;
-      const V3 s2 = cross(s, e1);
-      const float tnum = dot(s2, e2);
       const V3x2 s1 = cross(dn, splat(e2));
       const f32x2 se = dot(s1, splat(e1));
       const f32x2 inv = reciprocal_pair(se);
-      const f32x2 t = inv * splat(tnum);
-      const f32x2 b1 = inv * dot(s1, splat(s));
-      const f32x2 b2 = inv * dot(splat(s2), dn);
-      const f32x2 w = splat(1.0f) - b1 - b2;
       const f32x2 facing = dot(ndir, splat(n));
-      const bool hit_a = !(facing.x < 0) &&
-                         !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
-      const bool hit_b = !(facing.y < 0) &&
-                         !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
-      ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
-      bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
+      finish(o - p0, e1, e2, s1, inv, facing, k);
+      k++;
+      const int pair = __float_as_int(r.d0);  // 1 + the pair's number, 0: a triangle on its own
+      if (pair != 0) {
+        const float4 q0 = lds.pair_second[3 * pair - 3], q1 = lds.pair_second[3 * pair - 2],
+                     q2 = lds.pair_second[3 * pair - 1];
+        const V3x2 m1 = V3x2{negate_nonzero(s1.x), negate_nonzero(s1.y), negate_nonzero(s1.z)};
+        ba.nan_seen = ba.nan_seen || se.x == 0.0f;
+        bb.nan_seen = bb.nan_seen || se.y == 0.0f;
+        finish(o - xyz(q0), xyz(q1), xyz(q2), m1, inv, facing, k);
+        k++;
+      }
     }
     r = nx;
   }

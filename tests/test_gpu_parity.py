@@ -755,6 +755,42 @@ def test_device_tree_layout(rt, which):
     assert (np.sqrt(T, dtype=f32) >= r).all() and (np.sqrt(np.nextafter(T, f32(0)), dtype=f32) < r).all()
     if len(leaves) <= 80:  # sphere numbers exist where the scene can be staged in LDS
         assert np.array_equal(leaves[sph, 6].view(np.int32), np.arange(sph.sum(), dtype=np.int32))
+        # the fused kernel's record table: mirrored pairs are the neighbouring triangle leaves
+        # whose edges are each other's exact negations (zero components +0 in both, the others
+        # of magnitude in [2^-60, 2^60]) and whose normals agree; the second has no record
+        records, seconds = sg.read_pairs()
+        bits = leaves.view(np.uint32)
+
+        def mirrored(a, b):
+            if a == 0:
+                return b == 0
+            m = abs(float(np.array([a], np.uint32).view(f32)[0]))
+            return b == a ^ 0x80000000 and np.isfinite(m) and 2.0 ** -60 <= m <= 2.0 ** 60
+
+        want_records, want_seconds = [], []
+        k = 0
+        while k < len(leaves):
+            rec = leaves[k].copy()
+            if k + 1 < len(leaves) and not sph[k] and not sph[k + 1]:
+                ok = all(mirrored(int(bits[k, c]), int(bits[k + 1, c])) for c in (4, 5, 6, 8, 9, 10))
+                ok = ok and all(leaves[k, c] == leaves[k + 1, c] for c in (3, 7, 11))
+                if ok:
+                    want_seconds.append(leaves[k + 1, :12])
+                    rec[12] = np.array([len(want_seconds)], np.int32).view(f32)[0]
+                    k += 1
+            want_records.append(rec)
+            k += 1
+        assert np.array_equal(records.view(np.uint32), np.array(want_records, f32).view(np.uint32))
+        keep = [0, 1, 2, 4, 5, 6, 8, 9, 10]
+        assert len(seconds) == len(want_seconds)
+        if len(seconds):
+            assert np.array_equal(seconds[:, keep].view(np.uint32),
+                                  np.array(want_seconds, f32)[:, keep].view(np.uint32))
+        if which == "default":  # every wall of the reference's scene is a parallelogram split in two
+            assert len(seconds) == (~sph).sum() // 2 > 0
+    else:
+        records, seconds = sg.read_pairs()
+        assert len(records) == 0 and len(seconds) == 0
 
 
 def test_scene_create_rejects_malformed_trees(rt):
