@@ -64,6 +64,20 @@ struct Workspace {
   Counters *host_counters = nullptr;             // pinned
   BlockCounters *host_block_counters = nullptr;  // pinned
   size_t host_block_cap = 0;
+  float *host_rgb = nullptr;  // pinned: the framebuffer on its way to the caller's array
+  size_t host_rgb_cap = 0;
+  // A copy from the device straight into pageable memory goes through the runtime's own small
+  // staging buffers (2.4 ms for a 784 x 784 image); into pinned memory it runs at link speed,
+  // and the copy from there to the caller's array is a plain memcpy (0.9 ms together).
+  hipError_t reserve_host_rgb(size_t n) {
+    if (n <= host_rgb_cap) return hipSuccess;
+    if (host_rgb) (void)hipHostFree(host_rgb);
+    host_rgb = nullptr;
+    host_rgb_cap = 0;
+    hipError_t e = hipHostMalloc((void **)&host_rgb, n * sizeof(float));
+    if (e == hipSuccess) host_rgb_cap = n;
+    return e;
+  }
   void release() {
     pix_dir.release(); pix_hit.release(); pc_pos.release(); pc_nrm.release(); pc_wi.release();
     partial.release();
@@ -73,9 +87,12 @@ struct Workspace {
     block_counters.release();
     if (host_counters) (void)hipHostFree(host_counters);
     if (host_block_counters) (void)hipHostFree(host_block_counters);
+    if (host_rgb) (void)hipHostFree(host_rgb);
     host_counters = nullptr;
     host_block_counters = nullptr;
     host_block_cap = 0;
+    host_rgb = nullptr;
+    host_rgb_cap = 0;
   }
 };
 
@@ -1391,7 +1408,13 @@ int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *
   HIP_TRY(s->ws.rgb.reserve(n));
   int rc = rtr_render_pt_device(s, cam, prm, s->ws.rgb.ptr, stats);
   if (rc) return rc;
-  HIP_TRY(hipMemcpy(rgb, s->ws.rgb.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (s->ws.reserve_host_rgb(n) == hipSuccess) {
+    HIP_TRY(hipMemcpy(s->ws.host_rgb, s->ws.rgb.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    memcpy(rgb, s->ws.host_rgb, n * sizeof(float));
+  } else {
+    (void)hipGetLastError();  // no pinned memory to be had: the slower direct copy
+    HIP_TRY(hipMemcpy(rgb, s->ws.rgb.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+  }
   if (stats)
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
