@@ -190,7 +190,11 @@ int rtr_device_count(int *n);
 /*
  * Device self-test of the arithmetic shortcuts the kernels take where the reference
  * divides (no counterpart in the reference): the short reciprocal sequence used by the
- * triangle test is compared with the IEEE quotient 1.0f / d for all 2^32 floats.
+ * triangle test is compared with the IEEE quotient 1.0f / d for all 2^32 floats, the short
+ * square root of a normalisation with sqrtf for every float in [2^-100, 2^100), and the
+ * normalisation's quotients by way of a double-precision reciprocal with the IEEE quotients
+ * on 2^32 vectors built to be hard (components next to midpoint quotients, zeros, denormals,
+ * lengths outside the short path's range).
  * *mismatches = number of differing results; anything but 0 means this toolchain or
  * device does not reproduce the reference's arithmetic and results are not to be trusted.
  */

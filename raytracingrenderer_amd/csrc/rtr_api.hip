@@ -922,6 +922,13 @@ int rtr_self_test(int device, uint64_t *mismatches) {
   hipError_t e = hipMemset(d_bad, 0, sizeof(*d_bad));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_selftest_reciprocal, dim3(65536), dim3(kBlock), 0, nullptr, d_bad);
+    // every float in [2^-100, 2^100), a quarter of them per launch
+    const uint32_t lo = (127u - 100u) << 23, total = 200u << 23;
+    for (uint32_t done = 0; done < total; done += total / 4)
+      hipLaunchKernelGGL(k_selftest_sqrt, dim3(total / 4 / kBlock), dim3(kBlock), 0, nullptr, lo + done,
+                         total / 4, d_bad);
+    for (uint32_t round = 0; round < 16; round++)  // 2^32 vectors
+      hipLaunchKernelGGL(k_selftest_unit, dim3(1u << 20), dim3(kBlock), 0, nullptr, round * 7919u + 1u, d_bad);
     e = hipGetLastError();
   }
   unsigned long long bad = 0;

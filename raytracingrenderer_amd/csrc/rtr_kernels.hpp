@@ -276,6 +276,53 @@ k_selftest_reciprocal(unsigned long long *__restrict__ mismatches) {
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// sqrt_ranged against sqrtf for every float in [2^-100, 2^100): thread i of the launch takes
+// bit pattern lo + i (launched over the 200 * 2^23 patterns of that range).
+__global__ void __launch_bounds__(kBlock)
+k_selftest_sqrt(uint32_t lo, uint32_t count, unsigned long long *__restrict__ mismatches) {
+  const uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (i >= count) return;
+  const float s = __uint_as_float(lo + i);
+  if (__float_as_uint(sqrt_ranged(s)) != __float_as_uint(sqrtf(s))) atomicAdd(mismatches, 1ull);
+}
+// unit() against its IEEE form on vectors built to be hard: components next to the values
+// whose quotient by the length falls on a midpoint between two floats, plain random
+// components, zeros, and vectors outside the fast path's range (tiny and huge lengths,
+// components below 2^-60), for which the wave must fall back.
+RTR_DEV uint32_t selftest_mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ void __launch_bounds__(kBlock)
+k_selftest_unit(uint32_t round, unsigned long long *__restrict__ mismatches) {
+  const uint32_t id = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const uint32_t r0 = selftest_mix(id * 2654435761u + round), r1 = selftest_mix(r0 + 0x9e3779b9u),
+                 r2 = selftest_mix(r1 ^ round), r3 = selftest_mix(r2 + id);
+  // whole workgroups share a kind, so that some waves take the fast path and some do not
+  const uint32_t kind = blockIdx.x & 7u;
+  const int e = (kind == 6) ? -70 : (kind == 7) ? 70 : (int)(r0 % 41u) - 20;
+  const float scale = __uint_as_float((uint32_t)(127 + e) << 23);
+  V3 a = mk(__uint_as_float(0x3f000000u | (r1 >> 9)) * scale, __uint_as_float(0x3f000000u | (r2 >> 9)) * scale,
+            __uint_as_float(0x3f000000u | (r3 >> 9)) * scale);
+  if (r0 & 0x100u) a.x = -a.x;
+  if (r0 & 0x200u) a.y = -a.y;
+  if (kind == 1) a.z = (r0 & 0x400u) ? 0.0f : -0.0f;
+  if (kind == 2) { a.y = 0.0f; a.z = -0.0f; }
+  if (kind == 3) a.z = __uint_as_float(r3 & 0x807fffffu);  // a denormal or zero component
+  if (kind == 4 || kind == 5) {
+    // x next to q * l for q a midpoint between two floats below one
+    const float l0 = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    const uint32_t qb = 0x3e800000u | (r3 >> 10);
+    const double q = ((double)__uint_as_float(qb) + (double)__uint_as_float(qb + 1u)) * 0.5;
+    a.x = __uint_as_float(__float_as_uint((float)(q * (double)l0)) + (kind == 4 ? 0u : 1u));
+  }
+  const V3 got = unit(a);
+  const float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  const V3 want = mk(a.x / l, a.y / l, a.z / l);
+  auto differ = [](float g, float w) { return __float_as_uint(g) != __float_as_uint(w) && !(g != g && w != w); };
+  if (differ(got.x, want.x) || differ(got.y, want.y) || differ(got.z, want.z)) atomicAdd(mismatches, 1ull);
+}
+
 // ---- the algorithmic work of a ray batch ----
 // What the reference's traversal does for each ray, counted: boxes tested (every node the
 // recursion of src/BVH.cpp:66-80 enters), and triangles / spheres tested (leaves whose box

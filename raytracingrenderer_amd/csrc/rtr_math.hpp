@@ -33,9 +33,54 @@ RTR_DEV V3 cross(V3 a, V3 b) {
 }
 // include/Vector.h:79
 RTR_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-// include/Vector.h:84-87 -- three divisions by the length
+// RN(sqrt(s)) for a normal s in [2^-100, 2^100] without the range handling of sqrtf:
+// Markstein's sequence from the reciprocal square root (g -> sqrt(s), h -> 1 / (2 sqrt(s)),
+// one coupled refinement, one correction of g by its exact residual).  rtr_self_test compares
+// it with sqrtf for every float of that range.
+RTR_DEV float sqrt_ranged(float s) {
+  const float y = __builtin_amdgcn_rsqf(s);
+  float g = s * y, h = 0.5f * y;
+  const float r = __builtin_fmaf(-h, g, 0.5f);
+  g = __builtin_fmaf(g, r, g);
+  h = __builtin_fmaf(h, r, h);
+  const float d = __builtin_fmaf(-g, g, s);
+  return __builtin_fmaf(d, h, g);
+}
+// 1 / l in double precision to within an ulp: the hardware's estimate and two Newton steps
+RTR_DEV double reciprocal_f64(double l) {
+  double y = __builtin_amdgcn_rcp(l);
+  y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
+  return y;
+}
+RTR_DEV bool tiny_nonzero(float x) {  // 0 < |x| < 2^-60
+  return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < 0x21800000u - 1u;
+}
+// include/Vector.h:84-87 -- three divisions by the length.
+//
+// An IEEE fp32 division costs about fourteen plain instructions on gfx950 and sqrtf sixteen,
+// and the reference normalises eleven vectors per path vertex.  The quotients a / l of one
+// normalisation share l: with y = 1 / l in double precision (relative error below 2^-51),
+// (float)((double)a * y) is off a / l by less than 2^-50 of its size, and a quotient of two
+// fp32 numbers that is not itself an fp32 number lies at least 2^-49 of its size away from
+// the nearest midpoint between fp32 numbers (its distance from the midpoint, times the
+// denominator's significand, is a non-zero multiple of half an ulp) -- so the rounding to
+// fp32 lands on RN(a / l).  That bound needs a normal quotient: taken when, for every lane of
+// the wave, the sum of squares is in [2^-100, 2^100] and no component is a non-zero number
+// below 2^-60 (zeros are fine and common: wall normals); otherwise the IEEE operations.
+// rtr_self_test runs the quotients on adversarial operands (numerators next to midpoints).
 RTR_DEV V3 unit(V3 a) {
-  float l = length(a);
+  const float s = a.x * a.x + a.y * a.y + a.z * a.z;
+  bool ok = s >= 7.888609052210118e-31f && s <= 1.2676506002282294e30f;
+  const float least = fminf(fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
+  if (__ballot(least < 8.673617379884035e-19f) != 0)
+    ok = ok && !(tiny_nonzero(a.x) || tiny_nonzero(a.y) || tiny_nonzero(a.z));
+  if (__ballot(!ok) == 0) {
+    const float l = sqrt_ranged(s);
+    const double y = reciprocal_f64((double)l);
+    return mk((float)((double)a.x * y), (float)((double)a.y * y), (float)((double)a.z * y));
+  }
+  const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);
 }
 // std::max / std::min comparison directions (NaN behaviour differs from fmaxf)
