@@ -748,6 +748,8 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
         return fail(RTR_ERR_INVALID, "sphere light does not name a sphere prim");
       le_prim = z;
       z = d->prim_index[z];  // the kernels want the sphere's row
+      const float one_by_area = 1.0f / d->light_area[l];  // Sphere::sample's pdf, src/Sphere.cpp:47
+      memcpy(&w, &one_by_area, 4);
     } else if (kind == RTR_PRIM_TRIANGLE) {
       int b = d->light_tri_begin[l], e = d->light_tri_begin[l + 1];
       if (b < 0 || e < b || (e > b && !d->light_tris))

@@ -17,7 +17,8 @@ struct DeviceMaterial {  // 3 x float4
 };
 
 struct DeviceLights {
-  const float4 *light;        // per light: { area, bits(kind), bits(sphere row or tri_begin), bits(tri_end) }
+  const float4 *light;        // per light: { area, bits(kind), bits(sphere row), 1 / area } or
+                              //            { area, bits(kind), bits(tri_begin), bits(tri_end) }
   const float4 *light_le;     // per light: emission of the primitive its samples land on
   const int32_t *light_tris;  // triangle ROWS (not prim ids) in mesh leaf order
   const float *tri_area;      // per triangle row
@@ -180,7 +181,7 @@ struct LightSample {
 
 // Sphere::sample, src/Sphere.cpp:41-48 (theta is drawn before phi)
 template <class Tab, class Rng>
-RTR_DEV void sample_sphere(const Tab &T, int row, float area, Rng &rng, LightSample &ls) {
+RTR_DEV void sample_sphere(const Tab &T, int row, float one_by_area, Rng &rng, LightSample &ls) {
   float theta = (float)(2.0 * kPi * (double)rng.next());
   float phi = (float)(kPi * (double)rng.next());
   float st, ct, sp, cp;
@@ -191,7 +192,7 @@ RTR_DEV void sample_sphere(const Tab &T, int row, float area, Rng &rng, LightSam
   ls.pos = xyz(q) + q.w * d;
   ls.nrm = d;
   ls.leaf = (1 << 30) | row;
-  ls.pdf = 1.0f / area;
+  ls.pdf = one_by_area;  // 1.0f / area, divided once when the scene was uploaded
 }
 
 // Trangle::sample, src/Trangle.cpp:42-49
@@ -216,7 +217,7 @@ RTR_DEV void sample_object(const Tab &T, int l, Rng &rng, LightSample &ls) {
   float area = rec.x;
   ls.light = l;
   if (__float_as_int(rec.y) == 1) {
-    sample_sphere(T, __float_as_int(rec.z), area, rng, ls);
+    sample_sphere(T, __float_as_int(rec.z), rec.w, rng, ls);
     return;
   }
   ls.pdf = -1.0f;

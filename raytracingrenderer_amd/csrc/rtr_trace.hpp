@@ -1230,7 +1230,10 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
   // when qa is in [0.5, 2] and |n| is in [2^-40, 2^40]
   const bool a_fast = a_half && qa.x <= 2.0f && qa.y <= 2.0f;
-  f32x2 ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
+  // RN(1 / qa): qa in [0.5, 2] is well inside reciprocal_fast's range
+  f32x2 ya;
+  if (__ballot(!a_fast) == 0) ya = f32x2{reciprocal_fast(qa.x), reciprocal_fast(qa.y)};
+  else ya = f32x2{1.0f / qa.x, 1.0f / qa.y};
   asm volatile("" : "+v"(ya));  // formed once here, not again in every round of phase 2
   // Mirrored pairs.  Two triangles that split a parallelogram (p0 p1 p2 and p3 p2 p1, like every
   // wall of the reference's scene, src/main.cpp:26-39) have e1' = -e1 and e2' = -e2.  When two
