@@ -47,6 +47,9 @@ RTR_DEV float sqrt_ranged(float s) {
   return __builtin_fmaf(d, h, g);
 }
 // 1 / l in double precision to within an ulp: the hardware's estimate and two Newton steps
+// (the estimate is good to 2^-24.4 on the significands a float can have, measured over all
+// of them by tools/ubench/exact_unit.hip: one step would leave 2^-48.8, short of the 2^-50
+// that unit() needs)
 RTR_DEV double reciprocal_f64(double l) {
   double y = __builtin_amdgcn_rcp(l);
   y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
+#include <cmath>
+void report_rcp_error();
 
 __device__ __forceinline__ float sqrt_short(float s) {
   // Markstein's square root: y ~ 1/sqrt(s), then g -> sqrt(s), h -> 1/(2 sqrt(s))
@@ -71,6 +74,7 @@ __global__ void k_div(uint32_t round, unsigned long long *bad, uint32_t *first) 
 }
 
 int main() {
+  report_rcp_error();
   unsigned long long *bad, h = 0;
   uint32_t *first, hf[2] = {0, 0};
   (void)hipMalloc(&bad, 8); (void)hipMalloc(&first, 8);
@@ -84,9 +88,27 @@ int main() {
   (void)hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(hf, first, 8, hipMemcpyDeviceToHost);
   printf("square root, every float in [2^-100, 2^100): %llu mismatches (first at bits %08x)\n", h, hf[0]);
   (void)hipMemset(bad, 0, 8); (void)hipMemset(first, 0, 8);
-  const int rounds = 512;
+  const int rounds = 32;
   for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_div, dim3(1 << 20), dim3(256), 0, 0, (uint32_t)r * 7919u + 1u, bad, first);
   (void)hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(hf, first, 8, hipMemcpyDeviceToHost);
   printf("quotients, %.1f G pairs: %llu mismatches (first a %08x l %08x)\n", rounds * 268.435456e6 / 1e9, h, hf[0], hf[1]);
   return 0;
+}
+
+// The hardware's double-precision reciprocal estimate on the only arguments unit() gives it
+// (floats converted to double: 2^23 significands): largest |1 - l y0|, as bits of a double.
+__global__ void k_rcp_error(unsigned long long *worst) {
+  const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+  const double l = (double)__uint_as_float(0x3f800000u | m);
+  const double y0 = __builtin_amdgcn_rcp(l);
+  const double e = __builtin_fabs(__builtin_fma(-l, y0, 1.0));
+  atomicMax(worst, (unsigned long long)__double_as_longlong(e));
+}
+void report_rcp_error() {
+  unsigned long long *w, h = 0;
+  (void)hipMalloc(&w, 8); (void)hipMemset(w, 0, 8);
+  hipLaunchKernelGGL(k_rcp_error, dim3(1 << 15), dim3(256), 0, 0, w);
+  (void)hipMemcpy(&h, w, 8, hipMemcpyDeviceToHost);
+  double e; memcpy(&e, &h, 8);
+  printf("v_rcp_f64 on float significands: largest |1 - l y0| = %.3e = 2^%.2f\n", e, log2(e));
 }
