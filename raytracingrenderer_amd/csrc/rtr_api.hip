@@ -1235,11 +1235,14 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
   const bool fused = pl.fused;
   // upper bound of the pool; the exact size follows from the number of pixels
   // that need sampling (known after k_classify)
-  // (measured: 2^21 slots is best where the scene sits in LDS, 2^22 where traversal reads it
-  // from memory -- its launches then carry enough rays to amortise their tails; larger
-  // pools lose more in the path-logic kernels' cache behaviour than they gain)
+  // (measured: 2^21 slots is best where the scene sits in LDS; where traversal reads it from
+  // memory, 2^22 -- its launches then carry enough rays to amortise their tails -- and 2^23
+  // once the render is long enough for the larger launches to outweigh the longer drain at
+  // its end: 784 x 784 on a 1 M-triangle scene, 2^22 : 2^23 slots, 97 : 99 ms at 64 spp,
+  // 337 : 324 ms at 256 spp, 1297 : 1225 ms at 1024 spp)
+  const bool long_render = (uint64_t)a.n_pix * (uint64_t)a.spp >= ((uint64_t)1 << 27);
   size_t pool_target = prm->pool_size > 0 ? (size_t)prm->pool_size
-                                          : ((size_t)1 << (s->lds_geometry ? 21 : 22));
+                                          : ((size_t)1 << (s->lds_geometry ? 21 : long_render ? 23 : 22));
   size_t pool = pool_target;
   if (pool > max_units) pool = max_units;
   pool = (pool + (kLogicBlock * kGroup) - 1) / (kLogicBlock * kGroup) * (kLogicBlock * kGroup);
