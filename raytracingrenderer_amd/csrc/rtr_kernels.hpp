@@ -284,6 +284,11 @@ k_selftest_sqrt(uint32_t lo, uint32_t count, unsigned long long *__restrict__ mi
   if (i >= count) return;
   const float s = __uint_as_float(lo + i);
   if (__float_as_uint(sqrt_ranged(s)) != __float_as_uint(sqrtf(s))) atomicAdd(mismatches, 1ull);
+  if (i == 0) {
+    // near_light's constant: the first float whose root, as a double, is above 1e-3
+    const float t = near_light_threshold(), below = __uint_as_float(__float_as_uint(t) - 1u);
+    if (!((double)sqrtf(t) > 1e-3 && (double)sqrtf(below) <= 1e-3)) atomicAdd(mismatches, 1ull);
+  }
 }
 // unit() against its IEEE form on vectors built to be hard: components next to the values
 // whose quotient by the length falls on a midpoint between two floats, plain random
@@ -767,8 +772,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
       // next-event result: src/Render.cpp:95-107.  A miss arrives as a NaN point,
       // which fails the distance test like the reference's `testInter.hit` does.
       if (flags & kHasShadow) {
-        float dl = length(xyz(hs4) - xyz(h4));
-        if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
+        if (near_light(xyz(hs4) - xyz(h4))) {
           V3 term = xyz(g4) / (hs4.w * hs4.w) / g4.w;
           Lp = Lp + beta * term;
         }
@@ -1199,8 +1203,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       if (e.has_shadow && hs.leaf >= 0) {
         V3 hp, hn;
         hit_point_any<kLds>(sc, lds, hs, pos, ln, hp, hn);
-        float dl = length(hp - e.light_pos);
-        if ((double)dl >= -1e-3 && (double)dl <= 1e-3) {
+        if (near_light(hp - e.light_pos)) {
           V3 term = e.weight / (hs.t * hs.t) / e.light_pdf;
           const V3 add = beta * term;
           if constexpr (kLds) {

@@ -86,6 +86,14 @@ RTR_DEV V3 unit(V3 a) {
   const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);
 }
+// `disLen >= -1e-3 && disLen <= 1e-3` (src/Render.cpp:97-98) with disLen = |v| an fp32 length
+// compared as a double: the largest float not above 0.001 is 0x3a83126e, sqrtf is correctly
+// rounded and hence monotonic, and kNearLight2 is the smallest float whose root exceeds that
+// one -- so the test is  dot(v, v) < kNearLight2,  without the root (a NaN fails both forms;
+// rtr_self_test checks the constant against sqrtf).
+RTR_DEV float near_light_threshold() { return __uint_as_float(0x358637bdu); }
+RTR_DEV bool near_light(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z < near_light_threshold(); }
+
 // std::max / std::min comparison directions (NaN behaviour differs from fmaxf)
 RTR_DEV float maxf(float a, float b) { return (a < b) ? b : a; }
 RTR_DEV float minf(float a, float b) { return (b < a) ? b : a; }

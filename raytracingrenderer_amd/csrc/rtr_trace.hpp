@@ -1362,8 +1362,9 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
     const int bk = on_a ? ba.k : bb.k;
     const bool take = hit && (t < bt || (t == bt && k > bk));  // false for a NaN distance
     const bool ta = take && on_a, tb = take && !on_a;
-    ba.t = ta ? t : ba.t; ba.b1 = ta ? 0.0f : ba.b1; ba.b2 = ta ? 0.0f : ba.b2; ba.k = ta ? k : ba.k;
-    bb.t = tb ? t : bb.t; bb.b1 = tb ? 0.0f : bb.b1; bb.b2 = tb ? 0.0f : bb.b2; bb.k = tb ? k : bb.k;
+    // (b1, b2 keep what an earlier triangle left: nothing reads them for a sphere)
+    ba.t = ta ? t : ba.t; ba.k = ta ? k : ba.k;
+    bb.t = tb ? t : bb.t; bb.k = tb ? k : bb.k;
   }
   HitPair out;
   {
