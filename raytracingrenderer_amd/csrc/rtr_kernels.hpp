@@ -653,7 +653,9 @@ k_classify(RenderArgs a, DeviceScene sc, const DeviceMaterial *__restrict__ mats
     } else {
       pc.pos_mat[lp] = pack(mk(0, 0, 0), (uint32_t)mat);
     }
-    pc.wi[lp] = pack(-dn, wbits(dv));
+    // Material's unit(wi) of wi = -dir.normalize() (src/Render.cpp:82): the same for every
+    // sample of the pixel, so formed here once (shade_vertex<true> takes it as it is)
+    pc.wi[lp] = pack(unit(-dn), wbits(dv));
     if (!shade) {
       // every sample of this pixel returns `value` (src/Render.cpp:84-87); the
       // sums are still formed by repeated addition like the reference's loop
@@ -688,13 +690,19 @@ struct Emit {
   float light_pdf;
   V3 w1;         // extension ray direction
   V3 beta_next;  // path weight after the bounce (zero if the path stops here)
+  V3 uo_ext;     // unit(wn) as Material::eval formed it for the extension direction
 };
 
-template <class Tab>
+// kUnitWi: `wi` is unit(wi) already.  The reference's wi at a vertex reached by an extension ray
+// is the negated ray direction wn (src/Render.cpp:82), and Material::eval normalised that very
+// direction when the ray was made: unit(-wn) = -unit(wn) bit for bit (the length is the same
+// and IEEE division is odd in its numerator), so a caller that keeps e.uo_ext need not
+// normalise again; the first vertex of a sample has its unit(wi) formed once per work unit.
+template <bool kUnitWi = false, class Tab>
 RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi, V3 beta,
                           uint32_t mat, uint32_t gpix, uint32_t k, uint32_t depth, Emit &e) {
   DeviceMaterial dm = T.mat(mat);
-  const V3 ui = unit(wi), un = unit(N);  // shared by the two evaluations below
+  const V3 ui = kUnitWi ? wi : unit(wi), un = unit(N);  // shared by the two evaluations below
   VertexStream rng(a.seed, gpix, k, depth);
   LightSample ls;
   sample_light(T, rng, ls);
@@ -723,7 +731,7 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi
     float pdf = mat_pdf(dm);
     V3 w1 = unit(wo);
     e.wn = unit(w1);
-    e.beta_next = beta * mat_eval_units(dm, ui, e.wn, un) * dot(N, w1) / pdf / a.rr;
+    e.beta_next = beta * mat_eval_units(dm, ui, e.wn, un, e.uo_ext) * dot(N, w1) / pdf / a.rr;
     e.w1 = w1;
     e.has_ext = true;
   } else {
@@ -785,7 +793,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
           int m2 = sc.prim_material[prim2];
           if (!mat_emissive(mats[m2]) && !(a.max_depth > 0 && (int)depth + 1 >= a.max_depth)) {
             beta = xyz(i4);
-            wi = -unit(xyz(k4));
+            wi = -unit(unit(xyz(k4)));  // unit(wi) of wi = -unit(w1)
             N = xyz(he24);
             pos = xyz(he4);
             mat = (uint32_t)m2;
@@ -890,7 +898,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
   bool has_shadow = false, has_ext = false;
   if (live) {
     Emit e;
-    shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
+    shade_vertex<true>(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);  // wi: unit(wi)
     has_shadow = e.has_shadow;
     has_ext = e.has_ext;
     if (has_shadow) {
@@ -1132,7 +1140,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         us.fpos[0][tid] = pm.x; us.fpos[1][tid] = pm.y; us.fpos[2][tid] = pm.z;
         us.fmat[tid] = wbits(pm);
         us.fN[0][tid] = pn.x; us.fN[1][tid] = pn.y; us.fN[2][tid] = pn.z;
-        us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;
+        us.fwi[0][tid] = pw.x; us.fwi[1][tid] = pw.y; us.fwi[2][tid] = pw.z;  // unit(wi) already
         gpix = wbits(pw);
         us.out[tid] = chunk * cold.n_pix + lp;  // below 2^32: checked by the host
         k = chunk * cold.chunk_spp;
@@ -1163,10 +1171,12 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     Emit e;
     e.has_shadow = false; e.has_ext = false;
     e.light_pos = mk(0, 0, 0); e.weight = mk(0, 0, 0); e.beta_next = mk(0, 0, 0);
+    e.uo_ext = mk(0, 0, 0);
     e.light_pdf = 0;
     if (live) {
-      if (kLds) shade_vertex(a, LdsTables{lds, lsh, L.n_lights, L.total_area}, pos, N, wi, beta, mat, gpix, k, depth, e);
-      else shade_vertex(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
+      // (wi holds unit(wi) in this kernel)
+      if (kLds) shade_vertex<true>(a, LdsTables{lds, lsh, L.n_lights, L.total_area}, pos, N, wi, beta, mat, gpix, k, depth, e);
+      else shade_vertex<true>(a, GlobalTables{sc, L, mats}, pos, N, wi, beta, mat, gpix, k, depth, e);
       const uint32_t new_rays = (e.has_shadow ? 1u : 0u) + (e.has_ext ? 1u : 0u);
       if constexpr (kLds) {
         us.n_vertices[tid] += 1u;
@@ -1225,7 +1235,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
           V3 hp, hn;
           hit_point_any<kLds>(sc, lds, he, pos, wn, hp, hn);
           beta = e.beta_next;
-          wi = -wn;
+          wi = -e.uo_ext;
           N = unit(hn);
           pos = hp;
           mat = (uint32_t)m2;

@@ -112,11 +112,11 @@ RTR_DEV float smith_g(float roughness, V3 N, V3 V, V3 L) {
 // Material::eval, src/Material.cpp:66-95.  The reference normalises wi, wo and n
 // again in every branch; ui = unit(wi) and un = unit(n) are passed in so that a
 // vertex which evaluates its material twice forms them once.
-RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un) {
+RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un, V3 &uo) {
   V3 res = mk(0, 0, 0);
   int kind = mat_kind(m);
   V3 kd = xyz(m.kd_ior);
-  const V3 uo = unit(wo);
+  uo = unit(wo);  // handed back: the next vertex's unit(wi) is its negation
   if (kind == 0) {
     float c = dot(uo, un);
     float f = c > 0.0f ? (float)(1.0f / kPi) : 0.0f;
@@ -138,6 +138,10 @@ RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un) {
     }
   }
   return res;
+}
+RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un) {
+  V3 uo;
+  return mat_eval_units(m, ui, wo, un, uo);
 }
 RTR_DEV V3 mat_eval(const DeviceMaterial &m, V3 wi, V3 wo, V3 n) {
   return mat_eval_units(m, unit(wi), wo, unit(n));
