@@ -56,9 +56,10 @@ RTR_DEV double reciprocal_f64(double l) {
   y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
   return y;
 }
-RTR_DEV bool tiny_nonzero(float x) {  // 0 < |x| < 2^-60
-  return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < 0x21800000u - 1u;
+RTR_DEV bool tiny_below(float x, uint32_t limit_bits) {  // 0 < |x| < the float with these bits
+  return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < limit_bits - 1u;
 }
+RTR_DEV bool tiny_nonzero(float x) { return tiny_below(x, 0x21800000u); }  // 0 < |x| < 2^-60
 // include/Vector.h:84-87 -- three divisions by the length.
 //
 // An IEEE fp32 division costs about fourteen plain instructions on gfx950 and sqrtf sixteen,

@@ -657,7 +657,13 @@ RTR_DEV void hit_point(const DeviceScene &sc, const HitRec &h, V3 o, V3 dn, V3 &
 // development only: [0] wave iterations, [1] lane visits, [2] refills, [3] rays,
 // [4] test rounds, [5] pairs tested
 __device__ unsigned long long g_stream_stats[8];
-#define RTR_STAT(k, v) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_stream_stats[k], (unsigned long long)(v)); } while (0)
+// (v is evaluated by every lane, so that a ballot in it sees the whole wave)
+#ifdef RTR_CAUSE_STATS
+#define RTR_STAT(k, v) do { } while (0)
+#define RTR_CAUSE(k, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == 0) atomicAdd(&g_stream_stats[k], v_); } while (0)
+#else
+#define RTR_STAT(k, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == 0) atomicAdd(&g_stream_stats[k], v_); } while (0)
+#endif
 #else
 #define RTR_STAT(k, v) do { } while (0)
 #endif
@@ -997,6 +1003,26 @@ RTR_DEV LeafRecord load_leaf(const const_leaf *tab, int k) {
   return r;
 }
 
+// A leaf record on its way into sixteen scalar registers: leaf_fetch issues the load, leaf_ready
+// waits for it (for every scalar and LDS access the wave has in flight, that is), leaf_unpack
+// names the fields.  The compiler does not know that the registers are not valid in between:
+// a record must not be unpacked before leaf_ready.
+typedef int leaf_regs __attribute__((ext_vector_type(16)));
+RTR_DEV leaf_regs leaf_fetch(const const_leaf *rec) {
+  leaf_regs r;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(rec));
+  return r;
+}
+RTR_DEV void leaf_ready(leaf_regs &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+RTR_DEV LeafRecord leaf_unpack(const leaf_regs &v) {
+  LeafRecord r;
+  r.a0 = __int_as_float(v[0]); r.a1 = __int_as_float(v[1]); r.a2 = __int_as_float(v[2]); r.a3 = __int_as_float(v[3]);
+  r.b0 = __int_as_float(v[4]); r.b1 = __int_as_float(v[5]); r.b2 = __int_as_float(v[6]); r.b3 = __int_as_float(v[7]);
+  r.c0 = __int_as_float(v[8]); r.c1 = __int_as_float(v[9]); r.c2 = __int_as_float(v[10]); r.c3 = __int_as_float(v[11]);
+  r.d0 = __int_as_float(v[12]); r.d1 = __int_as_float(v[13]); r.node = v[14]; r.leaf = v[15];
+  return r;
+}
+
 RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid, V3 o, V3 dir,
                          V3 dn, MergeStack &merge) {
   const unsigned lane = threadIdx.x & 63u;
@@ -1165,19 +1191,16 @@ RTR_DEV int node_of_leaf(const LdsScene &lds, int n_nodes, int leaf) {
 struct BestHit {
   float t, b1, b2;
   int k;
-  bool nan_seen;
   RTR_DEV void init() {
     t = __int_as_float(0x7f800000);
     b1 = 0; b2 = 0;
     k = -1;
-    nan_seen = false;
   }
   // src/BVH.cpp:75-76 folded left to right -- the best hit is replaced unless it is strictly
-  // nearer -- for leaves that arrive in increasing k: "t <= best" (false for a NaN distance;
-  // best is +inf while nothing is hit, and never NaN).
-  RTR_DEV void fold_next(bool hit, float tt, float bb1, float bb2, int kk) {
-    nan_seen = nan_seen || (hit && tt != tt);
-    const bool take = hit && tt <= t;
+  // nearer -- for leaves that arrive in increasing k.  tt is the distance of a hit and NaN
+  // otherwise: "tt <= t" is false for a NaN (best is +inf while nothing is hit, and never NaN).
+  RTR_DEV void fold_next(float tt, float bb1, float bb2, int kk) {
+    const bool take = tt <= t;
     t = take ? tt : t;
     b1 = take ? bb1 : b1;
     b2 = take ? bb2 : b2;
@@ -1192,6 +1215,40 @@ RTR_DEV f32x2 negate_nonzero(f32x2 v) {
 RTR_DEV bool mirror_dir_ok(V3 d) {
   const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
   return fminf(fminf(ax, ay), az) >= kFastLo && fmaxf(fmaxf(ax, ay), az) <= 2.0f;
+}
+
+// The hardware's minimum / maximum of three (a NaN operand is passed over, like fminf does).
+// Written out because the compiler's fminf first re-canonicalises operands that come out of
+// packed arithmetic (one more instruction each at the rate of a compare).
+RTR_DEV float min3_raw(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+RTR_DEV float min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+RTR_DEV float min3_abs(float a, float b, float c) {  // min(a, |b|, |c|)
+  float r;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+RTR_DEV float max3_abs(float a, float b, float c) {  // max(a, |b|, |c|)
+  float r;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// keeps the compiler from folding a select into the comparisons around it (which would
+// bring the lane masks back into scalar registers and scalar instructions)
+RTR_DEV float opaque(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+RTR_DEV uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 // trace_all for two rays that leave the same point, in two phases.
@@ -1209,6 +1266,15 @@ RTR_DEV bool mirror_dir_ok(V3 d) {
 //    instead of one per sphere).  Leaves now arrive out of order, so the fold spells the
 //    tie rule out: the reference keeps, among equal distances, the LAST leaf in depth-first
 //    order ("replaced unless strictly nearer"), i.e. the larger k.
+//
+// Scalar instructions are the scarce resource of this loop (a scalar instruction holds its
+// wave up for longer than a vector instruction does, and four waves per SIMD do not hide
+// it: tools/ubench/issue_cycles.hip), so everything that decides per lane is kept in vector
+// registers: a hit is folded as "distance, or NaN for no hit", conditions that only switch a
+// test off become operands (+inf as the threshold of a triangle that faces away), and
+// whatever can only go wrong for a few rays in a billion (a reciprocal outside the short
+// sequence's range, a NaN or infinite distance) is accumulated and looked at once after the
+// pass: such a ray is re-traced by the literal tree evaluation.
 struct HitPair {
   HitRec a, b;
   int node_a, node_b;  // the leaves' node indices (-1 for a miss)
@@ -1250,121 +1316,202 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   //   1 / se' follows, and so does the facing test (normals equal as numbers: `< 0` of the
   //        sum does not see the sign of a zero term).
   // Everything else is computed from the second triangle's own data.  A ray outside the two
-  // conditions is marked like one that met a NaN distance and re-traced literally.
+  // conditions is re-traced literally.
   const const_leaf *items = (const const_leaf *)item_table;
-  if (has_pairs) {
-    ba.nan_seen = !mirror_dir_ok(dn_a);
-    bb.nan_seen = !mirror_dir_ok(dn_b);
-  }
-  auto finish = [&](V3 s, V3 e1, V3 e2, const V3x2 &s1, f32x2 inv, f32x2 facing, int k) {
+  // What the pass accumulates instead of deciding per triangle:
+  //  * se_lo, se_hi: the smallest and the largest |se| of both rays.  1 / se is always formed
+  //    by the short sequence (reciprocal_fast); when some |se| was outside its range [2^-60,
+  //    2^60] -- zero included -- both rays are re-traced.
+  //  * t_sum: the sum of all distances computed, per ray.  It is finite unless some distance
+  //    was a NaN or infinite (or the sum overflowed): then the ray is re-traced.  Within
+  //    reciprocal_fast's range and with a finite origin and direction a triangle's t, b1 and
+  //    b2 are finite, so a NaN distance cannot hide behind finite ones.
+  float se_lo = __int_as_float(0x7f800000), se_hi = 0.0f;
+  f32x2 t_sum = splat(0.0f);
+  const float inf = __int_as_float(0x7f800000), nan = __int_as_float(0x7fc00000);
+  // one triangle for both rays; thr: kTriEps, or +inf for a ray the triangle faces away from
+  // (then no finite minimum passes; an infinite one comes with an infinite t and a re-trace)
+  auto finish = [&](V3 s, V3 e1, V3 e2, const V3x2 &s1, f32x2 inv, f32x2 thr, int k) {
     const V3 s2 = cross(s, e1);
     const float tnum = dot(s2, e2);
     const f32x2 t = inv * splat(tnum);
     const f32x2 b1 = inv * dot(s1, splat(s));
     const f32x2 b2 = inv * dot(splat(s2), dn);
     const f32x2 w = splat(1.0f) - b1 - b2;
-    const bool hit_a = !(facing.x < 0) &&
-                       !(t.x < kTriEps || b1.x < kTriEps || b2.x < kTriEps || w.x < kTriEps);
-    const bool hit_b = !(facing.y < 0) &&
-                       !(t.y < kTriEps || b1.y < kTriEps || b2.y < kTriEps || w.y < kTriEps);
-    ba.fold_next(hit_a, t.x, b1.x, b2.x, k);
-    bb.fold_next(hit_b, t.y, b1.y, b2.y, k);
+    t_sum = t_sum + t;
+    // !(t < eps || b1 < eps || b2 < eps || w < eps), src/Trangle.cpp:17: a NaN fails no
+    // comparison there and is passed over by the minimum here
+    const float ma = min_raw(min3_raw(t.x, b1.x, b2.x), w.x);
+    const float mb = min_raw(min3_raw(t.y, b1.y, b2.y), w.y);
+    const float ta = opaque(!(ma < thr.x) ? t.x : nan);
+    const float tb = opaque(!(mb < thr.y) ? t.y : nan);
+    ba.fold_next(ta, b1.x, b2.x, k);
+    bb.fold_next(tb, b1.y, b2.y, k);
   };
-  LeafRecord r = load_leaf(items, 0);
+  // Sphere::intersect, src/Sphere.cpp:3-15, the cheap part.  A sphere behind the ray needs no
+  // second look: with the origin outside (cc > 0) and b > 0 the larger root is negative or a
+  // rounding error above zero -- sqrt(delta) is at most one ulp above b, so for b < 8192 and
+  // a >= 0.5 the root is below 2^-11 < 1e-3 and the reference's `t1 < 1e-3`
+  // (src/Sphere.cpp:19) rejects it.  "0 < b < 8192" is one unsigned comparison of the bit
+  // patterns: bits(b) - 1 < bits(8192) - 1 (a zero wraps around, negative numbers and NaNs
+  // have larger patterns); with the limit at 0 the comparison is switched off.
+  const uint32_t behind_limit = a_half ? 0x46000000u - 1u : 0u;
+  uint32_t sphere_bit = 1u;
+  auto mark_sphere = [&](const LeafRecord &r) {
+    const V3 oc = o - mk(r.a0, r.a1, r.a2);
+    const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+    const float cc = l2 - r.b0;
+    const f32x2 b = splat(2.0f) * (splat(oc.x) * dn.x + splat(oc.y) * dn.y + splat(oc.z) * dn.z);
+    const f32x2 delta = b * b - qa4 * splat(cc);
+    const uint32_t bit = opaque(!(l2 < r.b1) ? sphere_bit : 0u);  // origin outside
+    const uint32_t limit = opaque(cc > 0 ? behind_limit : 0u);
+    uint32_t ra = opaque((__float_as_uint(b.x) - 1u < limit) ? 0u : bit);
+    uint32_t rb = opaque((__float_as_uint(b.y) - 1u < limit) ? 0u : bit);
+    ra = opaque(delta.x < 0 ? 0u : ra);
+    rb = opaque(delta.y < 0 ? 0u : rb);
+    reach_a |= ra;
+    reach_b |= rb;
+    sphere_bit += sphere_bit;  // spheres are numbered in table order
+  };
+  auto test_triangles = [&](const LeafRecord &r, int k) {
+    // Trangle::intersect, src/Trangle.cpp:3-28
+    const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
+    const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
+    const V3x2 s1 = cross(dn, splat(e2));
+    const f32x2 se = dot(s1, splat(e1));
+    se_lo = min3_abs(se_lo, se.x, se.y);
+    se_hi = max3_abs(se_hi, se.x, se.y);
+    const f32x2 inv = f32x2{reciprocal_fast(se.x), reciprocal_fast(se.y)};
+    const f32x2 facing = dot(ndir, splat(n));
+    const f32x2 thr = f32x2{opaque(facing.x < 0 ? inf : kTriEps), opaque(facing.y < 0 ? inf : kTriEps)};
+    finish(o - p0, e1, e2, s1, inv, thr, k);
+    const int pair = __float_as_int(r.d0);  // 1 + the pair's number, 0: a triangle on its own
+    if (pair != 0) {
+      const float4 q0 = lds.pair_second[3 * pair - 3], q1 = lds.pair_second[3 * pair - 2],
+                   q2 = lds.pair_second[3 * pair - 1];
+      const V3x2 m1 = V3x2{negate_nonzero(s1.x), negate_nonzero(s1.y), negate_nonzero(s1.z)};
+      finish(o - xyz(q0), xyz(q1), xyz(q2), m1, inv, thr, k + 1);
+    }
+  };
   int k = 0;  // the leaf's number in depth-first leaf order
-  for (int i = 0; i < n_items; i++) {
-    const LeafRecord nx = load_leaf(items, i + 1);
+  auto process = [&](const LeafRecord &r) {
     if (r.leaf >> 30) {
-      // Sphere::intersect, src/Sphere.cpp:3-15
-      const V3 oc = o - mk(r.a0, r.a1, r.a2);
-      const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
-      const float cc = l2 - r.b0;
-      const bool outside = !(l2 < r.b1);
-      const f32x2 b = splat(2.0f) * (splat(oc.x) * dn.x + splat(oc.y) * dn.y + splat(oc.z) * dn.z);
-      const f32x2 delta = b * b - qa4 * splat(cc);
-      const uint32_t bit = 1u << __float_as_int(r.b2);
-      // A sphere behind the ray needs no second look: with the origin outside (cc > 0) and
-      // b > 0 the larger root is negative or a rounding error above zero -- sqrt(delta) is at
-      // most one ulp above b, so for b < 8192 and a >= 0.5 the root is below 2^-11 < 1e-3
-      // and the reference's `t1 < 1e-3` (src/Sphere.cpp:19) rejects it.
-      const bool behind_a = cc > 0 && b.x > 0 && b.x < 8192.0f && a_half;
-      const bool behind_b = cc > 0 && b.y > 0 && b.y < 8192.0f && a_half;
-      reach_a |= (valid_a && outside && !(delta.x < 0) && !behind_a) ? bit : 0u;
-      reach_b |= (valid_b && outside && !(delta.y < 0) && !behind_b) ? bit : 0u;
+      mark_sphere(r);
       k++;
     } else {
-      // Trangle::intersect, src/Trangle.cpp:3-28
-      const V3 p0 = mk(r.a0, r.a1, r.a2), n = mk(r.a3, r.b3, r.c3);
-      const V3 e1 = mk(r.b0, r.b1, r.b2), e2 = mk(r.c0, r.c1, r.c2);
-      const V3x2 s1 = cross(dn, splat(e2));
-      const f32x2 se = dot(s1, splat(e1));
-      const f32x2 inv = reciprocal_pair(se);
-      const f32x2 facing = dot(ndir, splat(n));
-      finish(o - p0, e1, e2, s1, inv, facing, k);
-      k++;
-      const int pair = __float_as_int(r.d0);  // 1 + the pair's number, 0: a triangle on its own
-      if (pair != 0) {
-        const float4 q0 = lds.pair_second[3 * pair - 3], q1 = lds.pair_second[3 * pair - 2],
-                     q2 = lds.pair_second[3 * pair - 1];
-        const V3x2 m1 = V3x2{negate_nonzero(s1.x), negate_nonzero(s1.y), negate_nonzero(s1.z)};
-        ba.nan_seen = ba.nan_seen || se.x == 0.0f;
-        bb.nan_seen = bb.nan_seen || se.y == 0.0f;
-        finish(o - xyz(q0), xyz(q1), xyz(q2), m1, inv, facing, k);
-        k++;
-      }
+      test_triangles(r, k);
+      k += __float_as_int(r.d0) != 0 ? 2 : 1;
     }
-    r = nx;
+  };
+  // Two records per trip, each fetched while the other is worked on and without copying a
+  // record from one set of scalar registers to another (the table ends with a padding
+  // record).  The fetch and the wait for it are written out: scalar loads return out of
+  // order, so any wait is for all of them, and left to itself the compiler moves a record's
+  // fetch (or part of it) down to its first use, where the wait then meets a load just issued.
+  // Here every wait is for a fetch issued one record earlier.
+  {
+    leaf_regs ra = leaf_fetch(items), rb;
+    int i = 0;
+    for (; i + 1 < n_items; i += 2) {
+      leaf_ready(ra);
+      rb = leaf_fetch(items + i + 1);
+#ifdef RTR_EXP_SALU  // development switch: extra scalar instructions per leaf record, to price them
+      {
+        unsigned xx;
+#pragma unroll
+        for (int qq = 0; qq < 2 * RTR_EXP_SALU; qq++) asm volatile("s_mov_b32 %0, 0" : "=s"(xx));
+      }
+#endif
+#ifdef RTR_EXP_VALU  // development switch: extra plain vector instructions per leaf record
+      {
+        float xx = 0;
+#pragma unroll
+        for (int qq = 0; qq < 2 * RTR_EXP_VALU; qq++) asm volatile("v_mov_b32 %0, 0" : "=v"(xx));
+      }
+#endif
+      process(leaf_unpack(ra));
+      leaf_ready(rb);
+      ra = leaf_fetch(items + i + 2);
+      process(leaf_unpack(rb));
+    }
+    leaf_ready(ra);
+    if (i < n_items) process(leaf_unpack(ra));
   }
+  reach_a = valid_a ? reach_a : 0u;
+  reach_b = valid_b ? reach_b : 0u;
   RTR_STAT(0, 1);
   RTR_STAT(3, __popcll(__ballot(valid_a)));
   RTR_STAT(4, __popcll(__ballot(valid_b)));
   RTR_STAT(5, __popcll(__ballot(valid_a || valid_b)));
-  // phase 2: the marked spheres, src/Sphere.cpp:3-39
-  for (;;) {
-    const bool on_a = reach_a != 0;
-    const uint32_t m = on_a ? reach_a : reach_b;
-    const bool act = m != 0;
-    if (__ballot(act) == 0) break;
-    RTR_STAT(1, 1);
-    RTR_STAT(2, __popcll(__ballot(act)));
-    const int j = act ? __ffs((int)m) - 1 : 0;
-    if (on_a) reach_a &= reach_a - 1u;
-    else reach_b &= reach_b - 1u;  // 0 stays 0
-    const float4 q = lds.sph_leaf[j], aux = lds.sph_aux[j];
-    const int k = __float_as_int(aux.z);
-    const V3 d = on_a ? dn_a : dn_b;
-    // the arithmetic of phase 1 again, for this lane's ray alone: same operations, same bits
-    const float a = on_a ? qa.x : qa.y;
-    const V3 oc = o - xyz(q);
-    const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
-    const float b = 2 * (oc.x * d.x + oc.y * d.y + oc.z * d.z);
-    const float cc = l2 - aux.x;
-    const float delta = b * b - 4 * a * cc;
-    const bool reach = act && !(l2 < aux.y) && !(delta < 0);
-    const float sq = sqrtf(delta);
-    const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
-    const bool slow = reach && !(a_fast && quotient_operand_fast(n1) && quotient_operand_fast(n2));
-    float t1, t2;
-    if (__ballot(slow) == 0) {
-      const float y = on_a ? ya.x : ya.y;
-      t1 = div_corrected(n1, a, y);
-      t2 = div_corrected(n2, a, y);
-    } else {
-      t1 = n1 / a;
-      t2 = n2 / a;
+  // phase 2: the marked spheres, src/Sphere.cpp:3-39 -- first the first ray's, then the second
+  // ray's (one loop for both would have every lane select its ray's direction, best hit and
+  // reciprocal by a lane mask, and write the result back through two more).
+  //  * sqrt(delta) by sqrt_ranged; d_lo, d_hi: the smallest and largest non-zero delta it was
+  //    given (its range is [2^-100, 2^100]; a marked sphere has delta >= 0);
+  //  * (-b +- sq) / 2 / a by div_corrected, which needs a in [0.5, 2] and a numerator that is
+  //    +0 or of magnitude in [2^-40, 2^40]: n_tiny is set by a numerator below 2^-40 that is not
+  //    zero, n_hi is the largest magnitude.  (+0 is common -- a ray that leaves a sphere it
+  //    sits on -- and goes through div_corrected as +0, like the IEEE quotient; -0 only comes
+  //    out of b = +0 and sq = +0, where the other root is +0 as well and the sphere is not
+  //    hit.)
+  //  * the distances go into t_sum like the triangles'.
+  float d_lo = inf, d_hi = 0.0f, n_hi = 0.0f;
+  uint32_t n_tiny = 0u;
+  auto marked_spheres = [&](uint32_t reach, V3 d, float a, float y, BestHit &best, float &tsum) {
+    for (;;) {
+      const bool act = reach != 0u;
+      if (__ballot(act) == 0) break;
+      RTR_STAT(1, 1);
+      RTR_STAT(2, __popcll(__ballot(act)));
+      const int j = act ? __ffs((int)reach) - 1 : 0;
+      reach &= reach - 1u;  // 0 stays 0
+      const float4 q = lds.sph_leaf[j], aux = lds.sph_aux[j];
+      const int k = __float_as_int(aux.z);
+      // the arithmetic of phase 1 again, for this ray alone: same operations, same bits
+      const V3 oc = o - xyz(q);
+      const float l2 = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+      const float b = 2 * (oc.x * d.x + oc.y * d.y + oc.z * d.z);
+      const float cc = l2 - aux.x;
+      // (a lane without a mark works on sphere 0 with a harmless discriminant)
+      const float delta = opaque(act ? b * b - 4 * a * cc : 1.0f);
+      // delta == 0 is not rare (a shadow ray that grazes the light: one light sample in a
+      // thousand): its root is 0, taken without the sequence
+      const bool grazing = delta == 0.0f;
+      const float ds = opaque(grazing ? 1.0f : delta);
+      d_lo = min_raw(d_lo, ds);
+      d_hi = max3_abs(d_hi, ds, ds);
+      const float sq = opaque(grazing ? delta : sqrt_ranged(ds));
+      const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
+      n_hi = max3_abs(n_hi, n1, n2);
+      n_tiny |= opaque((tiny_below(n1, 0x2b800000u) || tiny_below(n2, 0x2b800000u)) ? 1u : 0u);
+      const float t1 = div_corrected(n1, a, y);
+      const float t2 = div_corrected(n2, a, y);
+      const float t = (t2 < 0) ? t1 : t2;
+      tsum = tsum + (act ? t : 0.0f);
+      // a hit's distance, or NaN: no hit (src/Sphere.cpp:19), or a lane without a mark
+      float tt = opaque(!(t1 < kSphEps) ? t : nan);
+      tt = opaque(act ? tt : nan);
+      // equal distances: the later leaf wins (see above); then "tt <= best.t" decides
+      const int kk = opaque(tt == best.t ? (uint32_t)best.k : 0xffffffffu);
+      tt = opaque(k > kk ? tt : nan);
+      const bool take = tt <= best.t;
+      // (b1, b2 keep what an earlier triangle left: nothing reads them for a sphere)
+      best.t = take ? tt : best.t;
+      best.k = take ? k : best.k;
     }
-    const bool hit = reach && !(t1 < kSphEps);
-    const float t = (t2 < 0) ? t1 : t2;
-    const bool is_nan = t != t;
-    ba.nan_seen = ba.nan_seen || (hit && is_nan && on_a);
-    bb.nan_seen = bb.nan_seen || (hit && is_nan && !on_a);
-    const float bt = on_a ? ba.t : bb.t;
-    const int bk = on_a ? ba.k : bb.k;
-    const bool take = hit && (t < bt || (t == bt && k > bk));  // false for a NaN distance
-    const bool ta = take && on_a, tb = take && !on_a;
-    // (b1, b2 keep what an earlier triangle left: nothing reads them for a sphere)
-    ba.t = ta ? t : ba.t; ba.k = ta ? k : ba.k;
-    bb.t = tb ? t : bb.t; bb.k = tb ? k : bb.k;
+  };
+  float ts_a = t_sum.x, ts_b = t_sum.y;
+  marked_spheres(reach_a, dn_a, qa.x, ya.x, ba, ts_a);
+  marked_spheres(reach_b, dn_b, qa.y, ya.y, bb, ts_b);
+  // the verdict on the short cuts taken (`<` and `>=` are false for a NaN)
+  const bool shared_ok = se_lo >= 8.673617379884035e-19f && se_hi <= 1152921504606846976.0f &&  // 2^-60, 2^60
+                         d_lo >= 7.888609052210118e-31f && d_hi <= 1.2676506002282294e30f &&   // 2^-100, 2^100
+                         n_hi <= 1099511627776.0f && n_tiny == 0u &&                           // 2^40
+                         (a_fast || (reach_a | reach_b) == 0u);
+  bool retrace_a = !(shared_ok && fabsf(ts_a) < inf), retrace_b = !(shared_ok && fabsf(ts_b) < inf);
+  if (has_pairs) {
+    retrace_a = retrace_a || !mirror_dir_ok(dn_a);
+    retrace_b = retrace_b || !mirror_dir_ok(dn_b);
   }
   HitPair out;
   {
@@ -1394,8 +1541,21 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   };
   const bool ok_a = chain_ok(out.node_a, dn_a);
   const bool ok_b = chain_ok(out.node_b, dn_b);
-  unsigned long long need_a = __ballot(valid_a && (ba.nan_seen || !ok_a));
-  unsigned long long need_b = __ballot(valid_b && (bb.nan_seen || !ok_b));
+  unsigned long long need_a = __ballot(valid_a && (retrace_a || !ok_a));
+  unsigned long long need_b = __ballot(valid_b && (retrace_b || !ok_b));
+  RTR_STAT(6, __popcll(need_a) + __popcll(need_b));
+#ifdef RTR_CAUSE_STATS
+  RTR_CAUSE(6, __popcll(need_a) + __popcll(need_b));
+#endif
+#ifdef RTR_CAUSE_STATS  // development: why rays were flagged for the literal evaluation
+  RTR_CAUSE(0, 1);
+  RTR_CAUSE(1, __popcll(__ballot(!(se_lo >= 8.673617379884035e-19f && se_hi <= 1152921504606846976.0f))));
+  RTR_CAUSE(2, __popcll(__ballot(!(d_lo >= 7.888609052210118e-31f && d_hi <= 1.2676506002282294e30f))));
+  RTR_CAUSE(3, __popcll(__ballot(!(n_hi <= 1099511627776.0f))));
+  RTR_CAUSE(4, __popcll(__ballot(n_tiny != 0u)));
+  RTR_CAUSE(5, __popcll(__ballot(!(fabsf(ts_a) < inf) || !(fabsf(ts_b) < inf))));
+  RTR_CAUSE(7, __popcll(__ballot(!(a_fast || (reach_a | reach_b) == 0u))));
+#endif
   if (need_a | need_b) {
     LdsGeom g{lds.nodes, lds.tris, lds.sphs};
     while (need_a) {
