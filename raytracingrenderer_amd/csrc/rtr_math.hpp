@@ -34,11 +34,10 @@ RTR_DEV V3 cross(V3 a, V3 b) {
 // include/Vector.h:79
 RTR_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 // RN(sqrt(s)) for a normal s in [2^-100, 2^100] without the range handling of sqrtf:
-// Markstein's sequence from the reciprocal square root (g -> sqrt(s), h -> 1 / (2 sqrt(s)),
+// Markstein's sequence from the reciprocal square root y (g -> sqrt(s), h -> 1 / (2 sqrt(s)),
 // one coupled refinement, one correction of g by its exact residual).  rtr_self_test compares
 // it with sqrtf for every float of that range.
-RTR_DEV float sqrt_ranged(float s) {
-  const float y = __builtin_amdgcn_rsqf(s);
+RTR_DEV float sqrt_from_rsq(float s, float y) {
   float g = s * y, h = 0.5f * y;
   const float r = __builtin_fmaf(-h, g, 0.5f);
   g = __builtin_fmaf(g, r, g);
@@ -46,13 +45,14 @@ RTR_DEV float sqrt_ranged(float s) {
   const float d = __builtin_fmaf(-g, g, s);
   return __builtin_fmaf(d, h, g);
 }
-// 1 / l in double precision to within an ulp: the hardware's estimate and two Newton steps
-// (the estimate is good to 2^-24.4 on the significands a float can have, measured over all
-// of them by tools/ubench/exact_unit.hip: one step would leave 2^-48.8, short of the 2^-50
-// that unit() needs)
-RTR_DEV double reciprocal_f64(double l) {
-  double y = __builtin_amdgcn_rcp(l);
-  y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
+RTR_DEV float sqrt_ranged(float s) { return sqrt_from_rsq(s, __builtin_amdgcn_rsqf(s)); }
+// 1 / l in double precision to within an ulp, by two Newton steps from an estimate y0 that is good
+// to 2^-22: the estimate's error squares twice (2^-44, 2^-88), what is left is the rounding of the
+// last step.  unit() starts from the hardware's reciprocal square root of the sum of squares, which
+// it needs for the length anyway: that is within 2^-23 of 1 / sqrt(s), and l = RN(sqrt(s)) is within
+// 2^-24 of sqrt(s).
+RTR_DEV double reciprocal_f64_from(double l, double y0) {
+  double y = __builtin_fma(__builtin_fma(-l, y0, 1.0), y0, y0);
   y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
   return y;
 }
@@ -60,6 +60,11 @@ RTR_DEV bool tiny_below(float x, uint32_t limit_bits) {  // 0 < |x| < the float 
   return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < limit_bits - 1u;
 }
 RTR_DEV bool tiny_nonzero(float x) { return tiny_below(x, 0x21800000u); }  // 0 < |x| < 2^-60
+RTR_DEV uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // include/Vector.h:84-87 -- three divisions by the length.
 //
 // An IEEE fp32 division costs about fourteen plain instructions on gfx950 and sqrtf sixteen,
@@ -73,16 +78,24 @@ RTR_DEV bool tiny_nonzero(float x) { return tiny_below(x, 0x21800000u); }  // 0 
 // the wave, the sum of squares is in [2^-100, 2^100] and no component is a non-zero number
 // below 2^-60 (zeros are fine and common: wall normals); otherwise the IEEE operations.
 // rtr_self_test runs the quotients on adversarial operands (numerators next to midpoints).
+//
+// The guard is written for the instruction rates of gfx950 (tools/ubench/issue_cycles.hip:
+// additions and subtractions, integer ones included, issue at twice the rate of comparisons,
+// minima, shifts to the left and anything that reads a scalar register): x + x as integers
+// drops the sign and leaves twice the magnitude's bit pattern, one less wraps a zero around to
+// the largest number, the smallest of the three is below 2 * bits(2^-60) - 1 exactly when some
+// component is tiny and not zero; the range of s is one subtraction and one unsigned comparison.
 RTR_DEV V3 unit(V3 a) {
   const float s = a.x * a.x + a.y * a.y + a.z * a.z;
-  bool ok = s >= 7.888609052210118e-31f && s <= 1.2676506002282294e30f;
-  const float least = fminf(fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
-  if (__ballot(least < 8.673617379884035e-19f) != 0)
-    ok = ok && !(tiny_nonzero(a.x) || tiny_nonzero(a.y) || tiny_nonzero(a.z));
-  if (__ballot(!ok) == 0) {
-    const float l = sqrt_ranged(s);
-    const double y = reciprocal_f64((double)l);
-    return mk((float)((double)a.x * y), (float)((double)a.y * y), (float)((double)a.z * y));
+  const uint32_t bx = __float_as_uint(a.x), by = __float_as_uint(a.y), bz = __float_as_uint(a.z);
+  const uint32_t least = min3_u32(bx + bx - 1u, by + by - 1u, bz + bz - 1u);
+  // bits(2^-100) = 0x0d800000, bits(2^100) = 0x71800000: negative numbers and NaNs wrap or lie above
+  const bool bad = least < 2u * 0x21800000u - 1u || __float_as_uint(s) - 0x0d800000u > 0x71800000u - 0x0d800000u;
+  if (__ballot(bad) == 0) {
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float l = sqrt_from_rsq(s, y);
+    const double r = reciprocal_f64_from((double)l, (double)y);
+    return mk((float)((double)a.x * r), (float)((double)a.y * r), (float)((double)a.z * r));
   }
   const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);

@@ -78,6 +78,24 @@ enum Op {
   VALU4_SNOP1,   // 4 v_mul_f32 per s_nop 0
   VALU4_SMOV1,   // 4 v_mul_f32 per s_mov_b32
   CMP_SAND_SEL,  // v_cmp_lt_f32 vcc; s_and_b64 s, vcc, s; v_cndmask_b32_e64 (counted: 2 VALU)
+  ADD3_U32,      // v_add3_u32
+  LSHL_ADD_U32,  // v_lshl_add_u32
+  MIN_U32,       // v_min_u32
+  MIN3_U32,      // v_min3_u32
+  AND_OR_B32,    // v_and_or_b32
+  BFE_U32,       // v_bfe_u32
+  LSHR_B32,      // v_lshrrev_b32
+  CVT_F32_U32,   // v_cvt_f32_u32
+  CVT_I32_F32,   // v_cvt_i32_f32
+  FLOOR_F32,     // v_floor_f32
+  FREXP_EXP,     // v_frexp_exp_i32_f32
+  LDEXP_F32,     // v_ldexp_f32
+  CMP_LT_U32,    // v_cmp_lt_u32 vcc
+  ADD_CLAMP_U32, // v_add_u32 ... clamp (VOP3)
+  SUB_U32,       // v_sub_u32
+  MOV_DPP,       // v_mov_b32 row_shr:1 (DPP)
+  BPERMUTE,      // ds_bpermute_b32
+  RCP_F64,       // v_rcp_f64
   N_OPS
 };
 
@@ -93,12 +111,16 @@ static const char *op_name[N_OPS] = {
     "8 v_mul_f32 per same-address ds_read_b128 (counted: v_mul)", "ds_read_b128 same address", "ds_read_b128 per-lane address", "v_pk_mul_f32 (sgpr pair, op_sel broadcast)",
     "v_pk_fma_f32 (sgpr pair, op_sel broadcast)", "v_cndmask_b32_e64 sgpr mask alone", "s_and_b64 alone", "2 v_mul_f32 per s_and_b64 (counted: v_mul)",
     "4 v_mul_f32 per s_and_b64 (counted: v_mul)", "8 v_mul_f32 per s_and_b64 (counted: v_mul)", "4 v_mul_f32 per s_nop 0 (counted: v_mul)",
-    "4 v_mul_f32 per s_mov_b32 (counted: v_mul)", "v_cmp_lt_f32 vcc + s_and_b64 + v_cndmask_b32_e64 (counted: 2 VALU)"};
+    "4 v_mul_f32 per s_mov_b32 (counted: v_mul)", "v_cmp_lt_f32 vcc + s_and_b64 + v_cndmask_b32_e64 (counted: 2 VALU)",
+    "v_add3_u32", "v_lshl_add_u32", "v_min_u32", "v_min3_u32", "v_and_or_b32", "v_bfe_u32", "v_lshrrev_b32", "v_cvt_f32_u32", "v_cvt_i32_f32",
+    "v_floor_f32", "v_frexp_exp_i32_f32", "v_ldexp_f32", "v_cmp_lt_u32 vcc alone", "v_add_u32 clamp (VOP3)", "v_sub_u32", "v_mov_b32 dpp row_shr:1",
+    "ds_bpermute_b32", "v_rcp_f64"};
 
 // instructions counted per inner step (one step = one "operation" on one chain)
 static const int op_insts[N_OPS] = {1, 1, 1, 1, 1, 1, 2, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                    1, 1, 1, 1, 1, 1, 1, 1, 1, 2};
+                                    1, 1, 1, 1, 1, 1, 1, 1, 1, 2,
+                                    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 struct Stamp {
   unsigned long long t0, t1, r0, r1;
@@ -218,6 +240,24 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *stamps, float *sink, int i
             else asm volatile("s_and_b64 %0, %1, %1" : "=s"(m) : "s"(smask) : "scc");
           }
         }
+        if (OP == ADD3_U32) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c0), "v"(c1));
+        if (OP == LSHL_ADD_U32) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(c0));
+        if (OP == MIN_U32) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(c0));
+        if (OP == MIN3_U32) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c0), "v"(c1));
+        if (OP == AND_OR_B32) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c0), "v"(c1));
+        if (OP == BFE_U32) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(u[i]));
+        if (OP == LSHR_B32) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(u[i]));
+        if (OP == CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
+        if (OP == CVT_I32_F32) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[i]) : "v"(f[i]));
+        if (OP == FLOOR_F32) asm volatile("v_floor_f32 %0, %0" : "+v"(f[i]));
+        if (OP == FREXP_EXP) asm volatile("v_frexp_exp_i32_f32 %0, %1" : "=v"(u[i]) : "v"(f[i]));
+        if (OP == LDEXP_F32) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(f[i]) : "v"(lds_addr_same));
+        if (OP == CMP_LT_U32) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(u[i]), "v"(c0) : "vcc");
+        if (OP == ADD_CLAMP_U32) asm volatile("v_add_u32_e64 %0, %0, %1 clamp" : "+v"(u[i]) : "v"(c0));
+        if (OP == SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(c0));
+        if (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(f[i]) : "v"(g[i]));
+        if (OP == BPERMUTE) asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(q[i & 3].x) : "v"(lds_addr_lane), "v"(g[i]));
+        if (OP == RCP_F64) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
         if (OP == CMP_SAND_SEL) {
           unsigned long long m;
           asm volatile("v_cmp_lt_f32 vcc, %0, %2\n\ts_and_b64 %1, vcc, %4\n\ts_nop 0\n\tv_cndmask_b32_e64 %0, %2, %3, %1"
@@ -225,7 +265,7 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *stamps, float *sink, int i
         }
       }
     }
-    if (OP == VALU_LDS || OP == LDS_B128_SAME || OP == LDS_B128_LANE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (OP == VALU_LDS || OP == LDS_B128_SAME || OP == LDS_B128_LANE || OP == BPERMUTE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -370,6 +410,27 @@ int main(int argc, char **argv) {
     rc |= sweep<VALU4_SNOP1, 8>(d_stamps, d_sink, iters);
     rc |= sweep<VALU4_SMOV1, 8>(d_stamps, d_sink, iters);
     rc |= sweep<CMP_SAND_SEL, 8>(d_stamps, d_sink, iters);
+    return rc;
+  }
+  if (argc > 2 && atoi(argv[2]) == 4) {
+    rc |= sweep<ADD3_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<LSHL_ADD_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<MIN_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<MIN3_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<AND_OR_B32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<BFE_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<LSHR_B32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<CVT_F32_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<CVT_I32_F32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<FLOOR_F32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<FREXP_EXP, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<LDEXP_F32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<CMP_LT_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<ADD_CLAMP_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<SUB_U32, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<MOV_DPP, 8>(d_stamps, d_sink, iters);
+    rc |= sweep<BPERMUTE, 8>(d_stamps, d_sink, iters / 4);
+    rc |= sweep<RCP_F64, 8>(d_stamps, d_sink, iters);
     return rc;
   }
   rc |= sweep<FMA_VGPR, 8>(d_stamps, d_sink, iters);
