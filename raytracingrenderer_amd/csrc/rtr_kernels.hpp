@@ -285,6 +285,8 @@ k_selftest_sqrt(uint32_t lo, uint32_t count, unsigned long long *__restrict__ mi
   const float s = __uint_as_float(lo + i);
   if (__float_as_uint(sqrt_ranged(s)) != __float_as_uint(sqrtf(s))) atomicAdd(mismatches, 1ull);
   if (i == 0) {
+    const float ones = 1.0f / sqrtf(3.0f);  // (the compiler folds neither: IEEE operations on the device)
+    if (__float_as_uint(ones) != __float_as_uint(kUnitOfOnes)) atomicAdd(mismatches, 1ull);
     // near_light's constant: the first float whose root, as a double, is above 1e-3
     const float t = near_light_threshold(), below = __uint_as_float(__float_as_uint(t) - 1u);
     if (!((double)sqrtf(t) > 1e-3 && (double)sqrtf(below) <= 1e-3)) atomicAdd(mismatches, 1ull);
@@ -1107,7 +1109,10 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     us.n_rays[tid] = 0;
   }
 
+  SectionClock clk;
+  clk.start();
   for (;;) {
+    clk.mark(5);
     if (!live) {
       if (has_unit && k >= us.k_end[tid]) {
         const V3 acc = mk(us.acc[0][tid], us.acc[1][tid], us.acc[2][tid]);
@@ -1167,6 +1172,8 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       }
     }
     if (__ballot(live) == 0) break;
+    clk.mark(0);
+    clk.count(6);
 
     Emit e;
     e.has_shadow = false; e.has_ext = false;
@@ -1186,9 +1193,12 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         n_rays += new_rays;
       }
     }
-    if (!e.has_shadow) { e.l = mk(1, 1, 1); e.ln = unit(e.l); }
-    if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = unit(e.w1); }
+    // a lane without a shadow or an extension ray traces (1, 1, 1), whose normalisation is a constant:
+    // 1 / RN(sqrt(3)), rounded (checked against unit() by rtr_self_test)
+    if (!e.has_shadow) { e.l = mk(1, 1, 1); e.ln = mk(kUnitOfOnes, kUnitOfOnes, kUnitOfOnes); }
+    if (!e.has_ext) { e.w1 = mk(1, 1, 1); e.wn = mk(kUnitOfOnes, kUnitOfOnes, kUnitOfOnes); }
     const V3 ln = e.ln, wn = e.wn;
+    clk.mark(1);
     HitRec hs, he;
     int node_e = -1;
     if constexpr (kLds) {
@@ -1199,7 +1209,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
                                              wave_first((uint32_t)table));
       const HitPair hp = trace_all2(sc, items, (int)wave_first((uint32_t)cold.n_items),
                                     wave_first((uint32_t)cold.n_pairs) != 0u, lds, e.has_shadow, e.has_ext,
-                                    pos, e.l, ln, e.w1, wn, ws.merge);
+                                    pos, e.l, ln, e.w1, wn, ws.merge, clk);
       hs = hp.a;
       he = hp.b;
       node_e = hp.node_b;
@@ -1259,6 +1269,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       }
     }
   }
+  clk.flush();
   // statistics: one atomic pair per wave
   if constexpr (kLds) {
     n_vertices = us.n_vertices[tid];

@@ -87,6 +87,9 @@ RTR_DEV uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
 // component is tiny and not zero; the range of s is one subtraction and one unsigned comparison.
 RTR_DEV V3 unit(V3 a) {
   const float s = a.x * a.x + a.y * a.y + a.z * a.z;
+#ifdef RTR_EXP_CHEAP_UNIT  // development switch (wrong bits): what the exact normalisation costs
+  { const float y = __builtin_amdgcn_rsqf(s); return mk(a.x * y, a.y * y, a.z * y); }
+#endif
   const uint32_t bx = __float_as_uint(a.x), by = __float_as_uint(a.y), bz = __float_as_uint(a.z);
   const uint32_t least = min3_u32(bx + bx - 1u, by + by - 1u, bz + bz - 1u);
   // bits(2^-100) = 0x0d800000, bits(2^100) = 0x71800000: negative numbers and NaNs wrap or lie above
@@ -100,6 +103,8 @@ RTR_DEV V3 unit(V3 a) {
   const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);
 }
+// every component of unit((1, 1, 1)): 1 / RN(sqrt(3)) = 0x3f13cd3a
+constexpr float kUnitOfOnes = 0.5773502588272095f;
 // `disLen >= -1e-3 && disLen <= 1e-3` (src/Render.cpp:97-98) with disLen = |v| an fp32 length
 // compared as a double: the largest float not above 0.001 is 0x3a83126e, sqrtf is correctly
 // rounded and hence monotonic, and kNearLight2 is the smallest float whose root exceeds that
@@ -126,6 +131,9 @@ RTR_DEV uint32_t wbits(float4 v) { return __float_as_uint(v.w); }
 // what lets a CPU checker reproduce the kernels' sample values exactly; device
 // libm and host libm differ in the last ulp.
 RTR_DEV void sincos_fixed(float x, float &s_out, float &c_out) {
+#ifdef RTR_EXP_CHEAP_SINCOS  // development switch (wrong values)
+  s_out = x * 0.1f; c_out = 1.0f - x * 0.1f; return;
+#endif
   float kf = floorf(x * 0.636619772f + 0.5f);
   int k = (int)kf;
   float r = x - kf * 1.5703125f;
@@ -150,6 +158,11 @@ RTR_DEV void sincos_fixed(float x, float &s_out, float &c_out) {
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
 RTR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                            uint32_t k1, uint32_t out[4]) {
+#ifdef RTR_EXP_CHEAP_RNG  // development switch (a poor generator)
+  out[0] = c0 * 0x9E3779B9u + c1 + k0; out[1] = out[0] * 0x85EBCA6Bu + c2; out[2] = out[1] * 0xC2B2AE35u + c3; out[3] = out[2] * 0x27D4EB2Fu + k1;
+  out[0] ^= out[3] >> 15; out[1] ^= out[0] >> 13; out[2] ^= out[1] >> 16; out[3] ^= out[2] >> 14;
+  return;
+#endif
 #pragma unroll
   for (int r = 0; r < 10; r++) {
     // one 64-bit product per multiplier: a single v_mad_u64_u32 yields both halves

@@ -115,6 +115,9 @@ RTR_DEV float smith_g(float roughness, V3 N, V3 V, V3 L) {
 RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un, V3 &uo) {
   V3 res = mk(0, 0, 0);
   int kind = mat_kind(m);
+#ifdef RTR_EXP_NO_MICROFACET  // development switch (wrong image): what the microfacet branch costs
+  if (kind == 2) kind = 0;
+#endif
   V3 kd = xyz(m.kd_ior);
   uo = unit(wo);  // handed back: the next vertex's unit(wi) is its negation
   if (kind == 0) {

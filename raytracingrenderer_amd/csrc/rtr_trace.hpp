@@ -658,7 +658,10 @@ RTR_DEV void hit_point(const DeviceScene &sc, const HitRec &h, V3 o, V3 dn, V3 &
 // [4] test rounds, [5] pairs tested
 __device__ unsigned long long g_stream_stats[8];
 // (v is evaluated by every lane, so that a ballot in it sees the whole wave)
-#ifdef RTR_CAUSE_STATS
+#ifdef RTR_SECTION_TIMES
+#define RTR_STAT(k, v) do { } while (0)
+#define RTR_CAUSE(k, v) do { } while (0)
+#elif defined(RTR_CAUSE_STATS)
 #define RTR_STAT(k, v) do { } while (0)
 #define RTR_CAUSE(k, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == 0) atomicAdd(&g_stream_stats[k], v_); } while (0)
 #else
@@ -667,6 +670,22 @@ __device__ unsigned long long g_stream_stats[8];
 #else
 #define RTR_STAT(k, v) do { } while (0)
 #endif
+// Development only (-DRTR_STREAM_STATS -DRTR_SECTION_TIMES): shader cycles a wave spends in each
+// section of the fused kernel's round, summed over waves into g_stream_stats[0..5]; [6] rounds.
+struct SectionClock {
+#ifdef RTR_SECTION_TIMES
+  unsigned long long last, acc[7];
+  RTR_DEV void start() { last = __builtin_readcyclecounter(); for (int i = 0; i < 7; i++) acc[i] = 0; }
+  RTR_DEV void mark(int i) { const unsigned long long t = __builtin_readcyclecounter(); acc[i] += t - last; last = t; }
+  RTR_DEV void count(int i) { acc[i] += 1; }
+  RTR_DEV void flush() { if ((threadIdx.x & 63u) == 0) for (int i = 0; i < 7; i++) atomicAdd(&g_stream_stats[i], acc[i]); }
+#else
+  RTR_DEV void start() {}
+  RTR_DEV void mark(int) {}
+  RTR_DEV void count(int) {}
+  RTR_DEV void flush() {}
+#endif
+};
 
 RTR_DEV float lane_read(float v, unsigned src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
@@ -1282,7 +1301,7 @@ struct HitPair {
 
 RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int n_items, bool has_pairs,
                            const LdsScene &lds, bool valid_a, bool valid_b,
-                           V3 o, V3 dir_a, V3 dn_a, V3 dir_b, V3 dn_b, MergeStack &merge) {
+                           V3 o, V3 dir_a, V3 dn_a, V3 dir_b, V3 dn_b, MergeStack &merge, SectionClock &clk) {
   const unsigned lane = threadIdx.x & 63u;
   const V3x2 dir = pair(dir_a, dir_b), dn = pair(dn_a, dn_b);
   const V3x2 ndir = V3x2{-dir.x, -dir.y, -dir.z};
@@ -1439,6 +1458,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   }
   reach_a = valid_a ? reach_a : 0u;
   reach_b = valid_b ? reach_b : 0u;
+  clk.mark(2);
   RTR_STAT(0, 1);
   RTR_STAT(3, __popcll(__ballot(valid_a)));
   RTR_STAT(4, __popcll(__ballot(valid_b)));
@@ -1503,6 +1523,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   float ts_a = t_sum.x, ts_b = t_sum.y;
   marked_spheres(reach_a, dn_a, qa.x, ya.x, ba, ts_a);
   marked_spheres(reach_b, dn_b, qa.y, ya.y, bb, ts_b);
+  clk.mark(3);
   // the verdict on the short cuts taken (`<` and `>=` are false for a NaN)
   const bool shared_ok = se_lo >= 8.673617379884035e-19f && se_hi <= 1152921504606846976.0f &&  // 2^-60, 2^60
                          d_lo >= 7.888609052210118e-31f && d_hi <= 1.2676506002282294e30f &&   // 2^-100, 2^100
@@ -1575,6 +1596,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
       need_b &= need_b - 1;
     }
   }
+  clk.mark(4);
   return out;
 }
 
