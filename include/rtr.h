@@ -336,6 +336,9 @@ int rtr_stream_uniform(rtr_scene *scene, uint32_t seed, const uint32_t *pixel,
  * the fused kernel or the wavefront loop (rtr_render_params.mode).  rgb_out: n_columns*height*3 floats, pixel (i,j) of
  * the rendered columns at ((local column)*height + j)*3, i.e. the reference's
  * buffer index i*height+j when nothing is partitioned.  stats may be NULL.
+ * Every row is rendered.  (The reference, asked for fewer than 16 rows, renders row 0 only and
+ * leaves the others zero, src/Render.cpp:669-684: Render::renderPathTracing of the C++ mirror
+ * applies that rule to the buffer this call returns.)
  */
 int rtr_render_pt(rtr_scene *scene, const rtr_camera *camera, const rtr_render_params *params,
                   float *rgb_out, rtr_stats *stats);
@@ -347,20 +350,27 @@ int rtr_render_pt_device(rtr_scene *scene, const rtr_camera *camera,
                          const rtr_render_params *params, float *d_rgb_out, rtr_stats *stats);
 
 /*
- * rtr_render_pt_device for callers that cannot allocate (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
- * counterpart in the reference.  Same arguments, same image bit for bit (for the
- * same chunk_spp), and it calls no hipMalloc, hipFree or other allocating routine:
- * its device workspace (per-pixel records, the pixel list, partial sums, counters)
- * is a fixed 37 MiB array inside the library, of which every GPU the library runs
- * on holds one copy until the process ends.  Limits, rejected with RTR_ERR_INVALID
- * or RTR_ERR_UNSUPPORTED and a message: at most 2^18 pixels per call (512 x 512, or
- * one partition of a larger image), pixels x partial sums per pixel at most 2^20
- * (the default chunk_spp is chosen to fit), the fused kernel only (mode 0 or 2 on a
- * scene of at most 2^19 nodes), profile = 0.  stats gets what the host knows
+ * rtr_render_pt_device for callers that cannot allocate (tight serving loops, harnesses
+ * that forbid hipMalloc, code that must not disturb an allocator's state).  It has no
+ * counterpart in the reference.  Same arguments, and it calls no hipMalloc, hipFree or
+ * other allocating routine: its device workspace (per-pixel records, the pixel list,
+ * partial sums, counters) is a fixed 37 MiB array inside the library, of which every GPU
+ * the library runs on holds one copy until the process ends.
+ * The image equals rtr_render_pt_device's bit for bit when both run with the same
+ * chunk_spp.  With chunk_spp <= 0 the two calls choose DIFFERENT defaults (this one sizes
+ * its partial sums for the fixed array, 2^20 of them, the other for 2^27), and an image's
+ * low bits depend on how its samples are grouped into partial sums: read the value used
+ * from stats->chunk_spp and pass it to the other call to get the same bits.
+ * Limits, rejected with RTR_ERR_INVALID or RTR_ERR_UNSUPPORTED and a message: at most
+ * 2^18 pixels per call (512 x 512, or one partition of a larger image); pixels x partial
+ * sums per pixel at most 2^20 (the default chunk_spp is chosen to fit); the fused kernel
+ * only (mode RTR_MODE_FUSED on any scene, or RTR_MODE_AUTO on a scene of at most 2^19
+ * nodes, where it selects that kernel); profile = 0.  stats gets what the host knows
  * (samples, chunk_spp, n_columns, mode, ms_total); ray and vertex counts stay 0.
- * All calls on one GPU share the array, whatever scene they use: calls that
- * overlap on one GPU race.  Synchronises the scene's stream before returning.
+ * All calls on one GPU share the array, whatever scene they use: a call that arrives
+ * while another is in flight on the same GPU is refused with RTR_ERR_INVALID.  The work
+ * is enqueued on the library's stream of that GPU and the call synchronises that stream
+ * before returning, so it cannot be recorded into a HIP graph.
  */
 int rtr_render_pt_device_noalloc(rtr_scene *scene, const rtr_camera *camera,
                                  const rtr_render_params *params, float *d_rgb_out,
@@ -373,7 +383,8 @@ int rtr_render_pt_device_noalloc(rtr_scene *scene, const rtr_camera *camera,
  * handles must be distinct, devices may repeat) renders partition r of n_scenes --
  * interleaved tiles of params->tile_cols columns (<=0: the widest tile of at most 8
  * columns that gives every partition the same number of columns) -- on a host thread
- * and stream of its own, with no traffic between devices while rendering.  Then each
+ * of its own and on its device's streams, with no traffic between devices while rendering
+ * (partitions that share a device share that device's streams and run one after the other).  Then each
  * partition's framebuffer travels to scenes[0]'s device in ONE peer-to-peer copy on
  * its own stream (xGMI links are point to point, so every device uses its own link
  * to the root), and one kernel there puts the columns in image order.

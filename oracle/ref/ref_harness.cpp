@@ -347,4 +347,21 @@ int ref_render(void *h, unsigned W, unsigned H, unsigned spp, const char *file, 
   return 0;
 }
 
+/* Render::saveFile (src/Render.cpp:3-21) on a caller's float buffer of height * width pixels:
+ * writes <file>.ppm.  Returns 0 on success. */
+int ref_save_file(const float *rgb, unsigned height, unsigned width, const char *file) {
+  {
+    FILE *probe = fopen((std::string(file) + ".ppm").c_str(), "wb");
+    if (!probe) return -1; /* saveFile would dereference a null FILE* */
+    fclose(probe);
+  }
+  Render render;
+  render.buffer = new std::vector<Vector3f>((size_t)height * width);
+  for (size_t i = 0; i < (size_t)height * width; i++) (*render.buffer)[i] = v3(rgb + 3 * i);
+  render.saveFile(std::string(file), height, width);
+  delete render.buffer;
+  render.buffer = nullptr;
+  return 0;
+}
+
 } /* extern "C" */

@@ -148,8 +148,20 @@ def host_lib():
         L.rtrh_set_render_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.rtrh_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p,
                                   C.POINTER(RenderParams), _fp, C.POINTER(Stats)]
+        L.rtrh_save_file.argtypes = [_fp, C.c_uint, C.c_uint, C.c_char_p]
         _host = L
     return _host
+
+
+def save_ppm(rgb, height, width, file):
+    """Render::saveFile of the host library (reference src/Render.cpp:3-21) on a float buffer of
+    height * width pixels in the renderer's i * height + j order: writes <file>.ppm."""
+    L = host_lib()
+    rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    if len(rgb) != height * width:
+        raise ValueError("save_ppm: buffer does not hold height * width pixels")
+    if L.rtrh_save_file(rgb.ctypes.data_as(_fp), height, width, str(file).encode()) != 0:
+        raise RtrError("rtrh_save_file: %s" % L.rtrh_last_error().decode())
 
 
 def _f(a):
@@ -248,7 +260,7 @@ class HostScene:
     def build(self):
         if self.L.rtrh_build(self.h) != 0:
             self._herr("build")
-        self._dev = None
+        self._invalidate_device()
 
     @classmethod
     def from_spec(cls, spec):
@@ -281,7 +293,7 @@ class HostScene:
         hi = np.ascontiguousarray(hi, f32)
         if self.L.rtrh_set_node_box(self.h, int(flat_index), _f(lo), _f(hi)) != 0:
             raise RtrError("no node %d" % flat_index)
-        self._dev = None
+        self._invalidate_device()
 
     def num_prims(self):
         return self.L.rtrh_num_prims(self.h)
@@ -307,7 +319,13 @@ class HostScene:
     # ---- device: everything below calls the C ABI of include/rtr.h ----
     def set_device(self, index):
         self.L.rtrh_set_device(self.h, index)
+        self._invalidate_device()
+
+    def _invalidate_device(self):
+        """The scene changed: every upload of it is stale, the per-device replicas of
+        render_multi included (a later render_multi uploads again)."""
         self._dev = None
+        self.close_replicas()
 
     def flatten_for_upload(self):
         """Scene::flatten of the host mirror (cached there): the arrays rtr_scene_create takes."""

@@ -5,6 +5,7 @@
 #include "rtr_build.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -588,6 +589,8 @@ unsigned char *g_scratch_ptr[kMaxDevices] = {};
 
 // The scratch array's address on `device`, which must be the current device.  Resolved
 // once per device (scene creation does it, so that a render has nothing left to set up).
+constexpr int kNoAllocDevices = 64;  // a power of two, at least the GPUs of a node
+static std::atomic<int> g_noalloc_in_flight[kNoAllocDevices];
 int noalloc_scratch(int device, unsigned char **out) {
   if (device < 0 || device >= kMaxDevices) return fail(RTR_ERR_UNSUPPORTED, "device index beyond 63");
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -924,11 +927,13 @@ int rtr_self_test(int device, uint64_t *mismatches) {
   hipError_t e = hipMemset(d_bad, 0, sizeof(*d_bad));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_selftest_reciprocal, dim3(65536), dim3(kBlock), 0, nullptr, d_bad);
-    // every float in [2^-100, 2^100), a quarter of them per launch
+    // every float in [2^-100, 2^100], a quarter of them per launch (the last one takes 2^100 itself)
     const uint32_t lo = (127u - 100u) << 23, total = 200u << 23;
-    for (uint32_t done = 0; done < total; done += total / 4)
-      hipLaunchKernelGGL(k_selftest_sqrt, dim3(total / 4 / kBlock), dim3(kBlock), 0, nullptr, lo + done,
-                         total / 4, d_bad);
+    for (uint32_t done = 0; done < total; done += total / 4) {
+      const uint32_t count = total / 4 + (done + total / 4 == total ? 1u : 0u);
+      hipLaunchKernelGGL(k_selftest_sqrt, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, lo + done,
+                         count, d_bad);
+    }
     for (uint32_t round = 0; round < 16; round++)  // 2^32 vectors
       hipLaunchKernelGGL(k_selftest_unit, dim3(1u << 20), dim3(kBlock), 0, nullptr, round * 7919u + 1u, d_bad);
     e = hipGetLastError();
@@ -1455,6 +1460,15 @@ int rtr_render_pt_device_noalloc(rtr_scene *s, const rtr_camera *cam, const rtr_
   if (pl.a.n_pix == 0) return RTR_OK;
   if (!s->noalloc_scratch || s->fused_grid == 0)
     return fail(RTR_ERR_DEVICE, "scene was created without the scratch array's address");
+  // one call at a time per GPU: a second one would write over the first one's scratch array
+  struct InFlight {
+    std::atomic<int> &flag;
+    bool mine;
+    explicit InFlight(std::atomic<int> &f) : flag(f), mine(f.exchange(1) == 0) {}
+    ~InFlight() { if (mine) flag.store(0); }
+  } in_flight(g_noalloc_in_flight[s->device & (kNoAllocDevices - 1)]);
+  if (!in_flight.mine)
+    return fail(RTR_ERR_INVALID, "another rtr_render_pt_device_noalloc call is in flight on this GPU: they share one scratch array");
   DeviceGuard guard(s->device);
   hipStream_t st = s->stream;
   // Every call on this GPU shares the one array: the counters must start at zero (the front

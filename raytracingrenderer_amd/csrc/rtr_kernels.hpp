@@ -276,7 +276,7 @@ k_selftest_reciprocal(unsigned long long *__restrict__ mismatches) {
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
-// sqrt_ranged against sqrtf for every float in [2^-100, 2^100): thread i of the launch takes
+// sqrt_ranged against sqrtf for every float in [2^-100, 2^100]: thread i of the launch takes
 // bit pattern lo + i (launched over the 200 * 2^23 patterns of that range).
 __global__ void __launch_bounds__(kBlock)
 k_selftest_sqrt(uint32_t lo, uint32_t count, unsigned long long *__restrict__ mismatches) {

@@ -601,6 +601,12 @@ void Render::renderPathTracing(Scene &scene, const unsigned int &imageWidth,
                             &lastStats),
               "rtr_render_pt");
   }
+  // src/Render.cpp:669-684: with fewer than 16 rows the reference's row bands are empty
+  // (step = height / 16 = 0) and its one thread renders row 0 only; the other rows keep the
+  // zeros the buffer was created with.  The device renders every row; the rule is applied here.
+  if (imageHeight < 16)
+    for (size_t i = 0; i < (size_t)n_cols; i++)
+      for (size_t j = 1; j < imageHeight; j++) (*buffer)[i * imageHeight + j] = Vector3f();
   if (!fileName.empty()) saveFile(*buffer, fileName, imageHeight, (unsigned)n_cols);
   std::cout << "render end, spp = " << spp << "\n";
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count();
@@ -880,6 +886,16 @@ int rtrh_render(void *hs, unsigned W, unsigned H, unsigned spp, const char *file
     const std::vector<Vector3f> &b = h->render.getBuffer();
     if (rgb) memcpy(rgb, b.data(), b.size() * sizeof(Vector3f));
     if (stats) *stats = h->render.getStats();
+  });
+}
+
+// Render::saveFile on a caller's buffer of height * width pixels (three floats each)
+int rtrh_save_file(const float *rgb, unsigned height, unsigned width, const char *file) {
+  return guarded([&] {
+    if (!rgb || !file) throw std::invalid_argument("rtrh_save_file: null argument");
+    std::vector<Vector3f> px((size_t)height * width);
+    memcpy(px.data(), rgb, px.size() * sizeof(Vector3f));
+    Render::saveFile(px, std::string(file), height, width);
   });
 }
 

@@ -299,6 +299,7 @@ class Ref(_Backend):
         L.ref_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, _fp]
         L.ref_set_node_box.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         L.ref_create_photon_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint, _fp, _fp, _fp]
+        L.ref_save_file.argtypes = [_fp, C.c_uint, C.c_uint, C.c_char_p]
 
     def default_scene(self):
         return self.build_scene(default_scene_spec())
@@ -349,6 +350,16 @@ class Ref(_Backend):
         if rc != 0:
             raise RuntimeError("reference render failed to open output file")
         return rgb
+
+
+    def save_file(self, rgb, height, width, file="/tmp/ref_save"):
+        """Render::saveFile of the reference on a float buffer: the bytes of the PPM it writes."""
+        rgb = np.ascontiguousarray(rgb, f32).reshape(-1, 3)
+        assert len(rgb) == height * width
+        if self.lib.ref_save_file(_f(rgb), height, width, file.encode()) != 0:
+            raise RuntimeError("reference saveFile failed to open output file")
+        with open(file + ".ppm", "rb") as fh:
+            return fh.read()
 
 
 def have_ref():

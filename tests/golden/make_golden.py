@@ -14,6 +14,8 @@ outputs are data -- inputs and the reference's outputs -- never source text:
   lights_default.npz     Scene::samplingLight outputs + draws (default scene and a
                          multi-light scene with an emissive mesh)
   paths_default.npz      Render::pathTracing radiance for (ray, seed) pairs + the draws
+  tonemap.npz            Render::saveFile: a buffer of hard values (zero, one, beyond both, denormals,
+                         NaN, infinities, both sides of every 8-bit step) and the PPM the reference wrote
   ref_render_NxN_4096spp.npy        Render::renderPathTracing float buffer, N = 128 and 256
   ref_render_NxN_4096spp_noise.npy  RMSE between two independent such renders
 
@@ -73,6 +75,26 @@ def photon_maps(R):
     print("photon maps:", {k: v.shape for k, v in out.items()})
 
 
+def tonemap(R):
+    """Render::saveFile (src/Render.cpp:3-21) of the reference on values chosen to be hard for
+    `(unsigned char)(255 * pow(clamp(0, 1, v), 0.6f))`: around every step of the 8-bit output."""
+    vals = [0.0, -0.0, 1.0, 1.5, -1.0, 1e-45, -1e-45, 1e-40, 1.1754944e-38, np.nan, -np.nan, np.inf, -np.inf,
+            0.5, 0.25, 0.999999, 1.0000001, 3.4e38, -3.4e38]
+    v = np.array(vals, f32)
+    steps = ((np.arange(1, 256, dtype=np.float64) / 255.0) ** (1.0 / 0.6)).astype(f32)
+    near = [np.nextafter(steps, f32(2)), np.nextafter(steps, f32(-1))]
+    near += [np.nextafter(near[0], f32(2)), np.nextafter(near[1], f32(-1))]
+    rng = np.random.default_rng(77)
+    v = np.concatenate([v, steps] + near + [rng.random(3000).astype(f32) ** 3])
+    v = v[: len(v) // 6 * 6]
+    height, width = 6, len(v) // 18
+    px = v[: height * width * 3].reshape(-1, 3)
+    data = R.save_file(px, height, width, "/tmp/golden_tonemap")
+    np.savez_compressed(os.path.join(HERE, "tonemap.npz"), rgb=px, height=height, width=width,
+                        ppm=np.frombuffer(data, np.uint8))
+    print("tonemap:", px.shape, "ppm bytes", len(data), "header", data[:16])
+
+
 def converged_render(R, sr, size, keep_first=False):
     """Two independent 4096-spp renders of the reference: the first is the fixture, the RMSE
     between the two calibrates the tolerance of the test that uses it."""
@@ -105,9 +127,13 @@ def main():
     if "--only-render-256" in sys.argv:
         converged_render(R, sr, 256, keep_first="--keep-first" in sys.argv)
         return
+    if "--only-tonemap" in sys.argv:
+        tonemap(R)
+        return
     if "--only-photons" in sys.argv:
         photon_maps(R)
         return
+    tonemap(R)
     connectable(sr)
     if "--only-connectable" in sys.argv:
         return

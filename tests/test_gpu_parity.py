@@ -561,6 +561,39 @@ def test_host_api_render_and_ppm(rt, scenes, tmp_path):
     assert np.array_equal(body, want)
 
 
+def test_multi_device_render_after_the_scene_changed(rt):
+    """render_multi caches one upload per device; a change of the scene (here: one node's box
+    overwritten so that a wall triangle is no longer reached) must drop them, or the next render_multi
+    shows the old geometry."""
+    sg = rt.default_scene()
+    W, H, spp = 64, 48, 4
+    before, _ = sg.render_multi(W, H, spp, [0, 0], seed=4)
+    lo, hi, child, prim = sg.flatten()
+    leaf = int(np.nonzero(prim == 6)[0][0])  # the leaf of a wall triangle: a box far away hides it
+    sg.set_node_box(leaf, [1e6, 1e6, 1e6], [1e6 + 1, 1e6 + 1, 1e6 + 1])
+    single, _ = sg.render(W, H, spp, seed=4)
+    after, _ = sg.render_multi(W, H, spp, [0, 0], seed=4)
+    _assert_images_equal(after, single)
+    assert not _rays.same_bits(after, before).all()
+
+
+def test_host_api_fewer_than_sixteen_rows(rt, scenes):
+    """src/Render.cpp:669-684: below 16 rows the reference renders row 0 only and leaves the other
+    rows zero (tests/test_oracle_vs_ref.py::test_fewer_than_sixteen_rows).  The C ABI renders every
+    row; Render::renderPathTracing of the host mirror applies the reference's rule."""
+    O, so, sg = scenes
+    W, H, spp = 40, 8, 3
+    full, _ = sg.render(W, H, spp, seed=2)
+    host, _ = sg.render_via_host_api(W, H, spp, seed=2)
+    full, host = full.reshape(W, H, 3), host.reshape(W, H, 3)
+    assert full[:, 1:].any()
+    assert not host[:, 1:].any()
+    _assert_images_equal(host[:, 0], full[:, 0])
+    host16, _ = sg.render_via_host_api(W, 16, spp, seed=2)
+    full16, _ = sg.render(W, 16, spp, seed=2)
+    _assert_images_equal(host16, full16)
+
+
 # ---------------- several devices behind one call (rtr_render_pt_multi) ----------------
 def test_multi_device_render_equals_single_device(rt, scenes):
     """Virtual ranks: three uploads of the scene on device 0 render three partitions on three

@@ -319,3 +319,28 @@ def test_render_deterministic_pixels_match_reference(both, tmp_path):
     # and the rest agrees statistically (different random streams): mean within 15 %
     m_ref, m_got = ref[~fixed].mean(0), got[~fixed].mean(0)
     assert np.allclose(m_ref, m_got, rtol=0.15), (m_ref, m_got)
+    # the PPM the reference wrote on the way (src/Render.cpp:686 -> :3-21): header with the height
+    # first, then the buffer in its own order through the tone map
+    data = (tmp_path / "ref.ppm").read_bytes()
+    header = b"P6\n%d %d\n255\n" % (H, W)
+    assert data.startswith(header)
+    body = np.frombuffer(data[len(header):], np.uint8).reshape(-1, 3)
+    want = np.array([[O.lib.orc_tonemap(float(v)) for v in px] for px in ref], np.uint8)
+    assert np.array_equal(body, want)
+
+
+def test_fewer_than_sixteen_rows(both, tmp_path):
+    """src/Render.cpp:669-684: with height < 16 the reference's one thread renders row 0 only
+    (step = height / 16 = 0); rows 1... stay zero.  The checker renders every row -- the host
+    mirror applies the reference's rule on top (tests/test_gpu_parity.py) -- so row 0 is compared
+    on the pixels that do not depend on the random stream, and the rest must be zero."""
+    O, R, so, sr = both
+    W, H, spp = 64, 8, 2
+    ref = R.render(sr, W, H, spp, str(tmp_path / "ref8")).reshape(W, H, 3)
+    assert not ref[:, 1:].any()
+    assert ref[:, 0].any()
+    got = O.render(so, W, H, spp, seed=3, threads=1, recursive=True)[0].reshape(W, H, 3)
+    org, d = O.primary_rays(so, W, H)
+    prim = so.intersect(org, d)[0].reshape(W, H)
+    fixed = (prim[:, 0] == 0) | (prim[:, 0] < 0)
+    assert _rays.same_bits(got[:, 0][fixed], ref[:, 0][fixed]).all()

@@ -1,7 +1,8 @@
 """The render entry point that allocates nothing (rtr_render_pt_device_noalloc) against the
 allocating one (rtr_render_pt_device), through the C ABI: same image bit for bit, on two
 calls in a row that share the library's fixed scratch array, the second smaller than the
-first; and its limits are refused with a message."""
+first; its limits are refused with a message; and the device's free memory is the same
+before and after its calls, also when it is the first render a scene ever does."""
 import numpy as np
 import pytest
 
@@ -49,7 +50,23 @@ def test_no_alloc_render_equals_allocating_render():
     sw = rt.HostScene.from_spec(tg._random_scene_spec(5))
     _pair(sw, torch, 64, 48, 6, seed=8)
     _pair(sw, torch, 32, 16, 3, seed=8)
+    # "allocates nothing": the device's free memory does not move across its calls -- on a scene
+    # that has rendered before, and on a fresh one whose first render this is (nothing of the
+    # allocating call's workspace exists for it then)
     out = torch.zeros(3 * 600 * 600, dtype=torch.float32, device="cuda:0")
+    fresh = rt.default_scene()
+    fresh.device_scene()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for scene, (W, H, spp) in ((sg, (512, 512, 8)), (sg, (100, 60, 5)), (fresh, (512, 512, 4)), (fresh, (64, 64, 2)),
+                               (sw, (128, 128, 4))):
+        scene.render_device_noalloc(W, H, spp, out.data_ptr(), seed=9)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free0, (W, H, spp)
+    # (the allocating call does move it: the check above can fail)
+    fresh.render_device(512, 512, 4, out.data_ptr(), seed=9)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] < free0
     with pytest.raises(rt.RtrError, match="pixels"):
         sg.render_device_noalloc(600, 600, 4, out.data_ptr())
     with pytest.raises(rt.RtrError, match="chunk_spp"):
