@@ -4,13 +4,18 @@
 Workload (N=1): the reference's default Cornell-box scene (src/main.cpp:7-84),
 path tracing, 784x784 at 1024 spp (the configuration the headline metric is quoted on).  One "step" is one
 full render of that image; the scene is already resident in HBM when the timed
-region starts and the framebuffer stays in HBM (a torch tensor).
+region starts and the framebuffer stays in HBM (a torch tensor): `value` does not include
+the copy to the host that ends the reference's own wall time -- that rate is reported
+beside it as `value_with_framebuffer_on_host`.
 
 N>1 (launched by torch.distributed.run, one process per GPU): the same image is
 cut into interleaved column tiles (8 columns or fewer, so that every rank gets the same
 number of columns), rank r renders tiles t with t % N == r with
 no traffic between GPUs, and one gather (RCCL) brings the framebuffer to rank 0,
-which restores column order.  Total work is fixed, so "scaling" is "strong".
+which restores column order with one indexed copy.  Total work is fixed, so "scaling" is
+"strong".  The line then also carries, per rank, the time its renders took and what the
+gather cost, and one more record: the 2048 x 2048 image at 4096 spp (the configuration the
+scaling curve is specified on) rendered once by the same ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -207,6 +212,9 @@ def main():
                     help="rank 0 saves the last step's whole image (W*H x 3 float32, .npy) here")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other measurement inputs reported after the headline line's timing")
+    ap.add_argument("--big", default="2048x2048x4096",
+                    help="N > 1: WxHxSPP of the one render added as an extra record (the configuration the "
+                         "scaling curve is specified on)")
     ap.add_argument("--pool", type=int, default=0, help="path pool size (0 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="samples per partial sum (0 = default)")
     ap.add_argument("--mode", type=int, default=0,
@@ -251,21 +259,26 @@ def main():
 
     agg = {"rays": 0, "vertices": 0, "ms_trace": 0.0, "ms_logic": 0.0, "ms_other": 0.0,
            "ms_fused": 0.0, "trace_launches": 0, "fused_launches": 0, "iterations": 0,
-           "samples": 0, "mode": 0}
+           "samples": 0, "mode": 0, "render_ms": 0.0, "gather_ms": 0.0}
 
     last = {"image": None}
 
     def step(record):
+        t_a = time.perf_counter()
         st = scene.render_device(W, H, spp, local.data_ptr(), seed=args.seed, part_index=rank,
                                  part_count=world, tile_cols=tile, profile=True,
                                  pool_size=args.pool, chunk_spp=args.chunk, mode=args.mode,
-                                 streams=args.streams)
+                                 streams=args.streams)  # returns when this rank's columns are done
+        t_b = time.perf_counter()
         if gather is not None:
-            last["image"] = gather(local)  # one RCCL gather + column re-ordering on rank 0
+            last["image"] = gather(local)  # one RCCL gather + one indexed copy on rank 0
             # the gather reads `local` on torch's stream, the next render writes it on the
             # library's: wait for the gather before going on
             torch.cuda.current_stream(dev).synchronize()
+        t_c = time.perf_counter()
         if record:
+            agg["render_ms"] += (t_b - t_a) * 1e3
+            agg["gather_ms"] += (t_c - t_b) * 1e3  # includes waiting for the slowest rank
             agg["rays"] += st.rays
             agg["vertices"] += st.vertices
             agg["ms_trace"] += st.ms_trace
@@ -305,6 +318,42 @@ def main():
     else:
         rays_total, vert_total = float(t[1]), float(t[2])
 
+    # what each rank's renders took, and what the gather cost it (per step)
+    mine = torch.tensor([agg["render_ms"] / max(1, args.steps), agg["gather_ms"] / max(1, args.steps)],
+                        dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)] if collective else [mine]
+    if collective:
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(x[0]), float(x[1])] for x in per_rank]
+
+    big = None
+    if collective and not args.no_extras:
+        # the configuration the scaling curve is specified on, once, by the same ranks
+        W2, H2, spp2 = (int(x) for x in args.big.lower().split("x"))
+        tile2 = next((t for t in (8, 7, 6, 5, 4, 3, 2, 1) if W2 % t == 0 and (W2 // t) % world == 0), 8)
+        local2 = local_buffer(torch, W2, H2, world, tile2, dev)
+        gather2 = ColumnGather(torch, dist, W2, H2, rank, world, tile2, dev, dst=0, always_collective=True)
+        scene.render_device(W2, H2, 8, local2.data_ptr(), seed=args.seed, part_index=rank, part_count=world,
+                            tile_cols=tile2)
+        fence()
+        t_a = time.perf_counter()
+        scene.render_device(W2, H2, spp2, local2.data_ptr(), seed=args.seed, part_index=rank,
+                            part_count=world, tile_cols=tile2)
+        t_b = time.perf_counter()
+        gather2(local2)
+        fence()
+        t_c = time.perf_counter()
+        mine2 = torch.tensor([(t_b - t_a) * 1e3, (t_c - t_a) * 1e3], dtype=torch.float64, device=dev)
+        all2 = [mine2.clone() for _ in range(world)]
+        dist.all_gather(all2, mine2)
+        renders = [float(x[0]) for x in all2]
+        wall = max(float(x[1]) for x in all2)
+        big = {"workload": "default Cornell box, %dx%d at %d spp, %d rank(s), one gather" % (W2, H2, spp2, world),
+               "ms": wall, "msamples_per_s": W2 * H2 * spp2 / wall / 1e3, "tile_cols": tile2,
+               "per_rank_render_ms": renders, "imbalance_max_over_mean": max(renders) / (sum(renders) / len(renders)),
+               "gather_and_wait_ms_rank0": float(all2[0][1]) - float(all2[0][0])}
+        del local2, gather2
+
     if rank == 0 and args.dump_image:
         img = last["image"] if last["image"] is not None else local[: W * H]
         np.save(args.dump_image, img.reshape(-1, 3).cpu().numpy())
@@ -333,7 +382,7 @@ def main():
         rays_per_launch = queries
         tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03", "traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
@@ -347,23 +396,30 @@ def main():
                     "flop_per_query": FLOP_PER_QUERY, "flop_per_vertex": FLOP_PER_VERTEX,
                     "note": "fp32 VALU-issue bound (the 37-node scene sits in LDS and the "
                             "scalar cache); parity forbids FMA contraction, so at most half "
-                            "of the FMA-counted peak is reachable"}
-        if fused and traffic is not None:
-            # Issue rate: wave-level vector instructions of one launch (SQ_INSTS_VALU of a separate
-            # counter pass, profiles/) over the 1024 SIMDs and the launch's duration, against what
-            # tools/ubench/valu_rates.hip measures for independent v_fma_f32 / v_mul_f32 at four
-            # waves per SIMD (1.35 ns; a packed instruction takes 2.74 ns, v_rcp_f32 4.4 ns)
+                            "of the FMA-counted peak is reachable.  `traffic` is not measured in this "
+                            "run: it is the FETCH_SIZE x 2 + WRITE_SIZE of the committed counter passes "
+                            "over this command (profiles/r03/traffic.json)"}
+        if fused and avg_ms > 0:
+            # Issue account: the launch's wave-level instruction counts by class (SQ_INSTS_* of
+            # committed counter passes) priced with the cycles per instruction and SIMD that
+            # tools/ubench/issue_cycles.hip measures for each class at four waves per SIMD
+            # (tools/issue_account.py -> profiles/r03/issue_account.json); nothing is a literal here.
             try:
-                n_inst = json.load(open(tpath)).get(kernel + "_valu_instructions_per_launch")
+                acc = json.load(open(os.path.join(ROOT, "profiles", "r03", "issue_account.json")))
+                scale = float(W) * H * spp / acc["samples_counted"]
+                n_inst = acc["valu_instructions"] * scale
+                ns = avg_ms * 1e6 / (n_inst / 1024.0)
+                floor_ns = acc["floor_cycles_of_this_mix_per_simd"] * scale / acc["shader_ghz"]
+                roofline["vector_issue"] = {
+                    "valu_instructions_per_launch": n_inst,
+                    "ns_per_wave_instruction_and_simd": ns,
+                    "plain_fp32_floor_ns": acc["plain_fp32_cycles"] / acc["shader_ghz"],
+                    "plain_fp32_floor_cycles": acc["plain_fp32_cycles"],
+                    "floor_of_this_instruction_mix_ms": floor_ns * 1e-6,
+                    "frac_of_mix_floor": floor_ns * 1e-6 / avg_ms,
+                    "source": "profiles/r03/issue_account.json"}
             except Exception:
-                n_inst = None
-            if n_inst and avg_ms > 0:
-                scale = float(W) * H * spp / (784.0 * 784.0 * 1024.0)  # counted on the default workload
-                ns = avg_ms * 1e6 / (n_inst * scale / 1024.0)
-                roofline["vector_issue"] = {"ns_per_wave_instruction_and_simd": ns,
-                                            "measured_floor_ns_plain_fp32": 1.35,
-                                            "frac_of_measured_issue_rate": 1.35 / ns,
-                                            "valu_instructions_per_launch": n_inst * scale}
+                pass
         if fused:
             # nothing streams through HBM in this kernel by design (path state, rays and hits
             # stay in registers): per work unit (pixel x chunk of samples) it reads the pixel's
@@ -380,7 +436,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "default Cornell box (reference src/main.cpp), path tracing, "
-                                   "%dx%d at %d spp" % (W, H, spp),
+                                   "%dx%d at %d spp; scene resident and framebuffer left in HBM (with the "
+                                   "copy to the host: value_with_framebuffer_on_host)" % (W, H, spp),
                        "width": W, "height": H, "spp": spp,
                        "parallelism": "columns, %d-col interleaved tiles x %d gpu, 1 gather" % (tile, world)},
             "mrays_per_s_unique": rays_total / elapsed / 1e6,
@@ -395,7 +452,18 @@ def main():
                                          "other": agg["ms_other"] / args.steps},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_extras:
+        if collective:
+            renders = [x[0] for x in per_rank]
+            out["multi_gpu"] = {"tile_cols": tile, "per_rank_render_ms": renders,
+                                "render_ms_min": min(renders), "render_ms_max": max(renders),
+                                "imbalance_max_over_mean": max(renders) / (sum(renders) / len(renders)),
+                                "gather_and_wait_ms_per_rank": [x[1] for x in per_rank],
+                                "gather_ms": min(x[1] for x in per_rank),
+                                "note": "per step; a rank's gather time includes waiting for the slowest "
+                                        "rank, so the smallest one is what the gather itself costs"}
+            if big is not None:
+                out["extra"] = [big]
+        if not collective and not args.no_extras:
             # the reference's wall ends with the framebuffer on the host: the same render
             # through the host-output entry point (one D2H copy more)
             try:
@@ -409,7 +477,7 @@ def main():
                                                          "unit": "Msamples/s", "ms": dt * 1e3}
             except Exception as e:
                 out["value_with_framebuffer_on_host"] = {"value": None, "error": repr(e)}
-        if world == 1 and not args.no_extras:
+        if not collective and not args.no_extras:
             try:
                 out["extra"] = extras(torch, rt, dev, args.seed)
             except Exception as e:  # reports, never a reason to lose the line

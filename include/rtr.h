@@ -182,6 +182,9 @@ typedef struct rtr_stats {
   /* wavefront loop on scenes read from memory: box tests and primitive tests its traversal
      launches made (the primary rays' launch not included); 0 elsewhere */
   uint64_t boxes_tested, prims_tested;
+  /* rtr_render_pt_multi: the fastest and the slowest partition's own ms_total (what the join of
+     src/Render.cpp:677-679 waits for is the slowest); the single-device calls put ms_total in both */
+  double ms_render_min, ms_render_max;
 } rtr_stats;
 
 const char *rtr_last_error(void);

@@ -47,7 +47,8 @@ class Stats(C.Structure):
                 ("trace_launches", C.c_uint64), ("ms_fused", C.c_double),
                 ("fused_launches", C.c_uint64), ("ms_gather", C.c_double),
                 ("n_devices", C.c_int32), ("reserved", C.c_int32),
-                ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64)]
+                ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64),
+                ("ms_render_min", C.c_double), ("ms_render_max", C.c_double)]
 
 
 class Camera(C.Structure):

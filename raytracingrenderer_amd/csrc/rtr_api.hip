@@ -1413,6 +1413,7 @@ int rtr_render_pt_device(rtr_scene *s, const rtr_camera *cam, const rtr_render_p
     stats->prims_tested = ws.host_counters->prims;
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    stats->ms_render_min = stats->ms_render_max = stats->ms_total;
   }
   return RTR_OK;
 }
@@ -1437,9 +1438,11 @@ int rtr_render_pt(rtr_scene *s, const rtr_camera *cam, const rtr_render_params *
     (void)hipGetLastError();  // no pinned memory to be had: the slower direct copy
     HIP_TRY(hipMemcpy(rgb, s->ws.rgb.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
   }
-  if (stats)
+  if (stats) {
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    stats->ms_render_min = stats->ms_render_max = stats->ms_total;
+  }
   return RTR_OK;
 }
 
@@ -1493,6 +1496,7 @@ int rtr_render_pt_device_noalloc(rtr_scene *s, const rtr_camera *cam, const rtr_
     stats->n_devices = 1;
     stats->ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    stats->ms_render_min = stats->ms_render_max = stats->ms_total;
   }
   return RTR_OK;
 }
@@ -1638,6 +1642,12 @@ static int render_multi(rtr_scene *const *scenes, int32_t n_scenes, const rtr_ca
       stats->ms_logic = std::max(stats->ms_logic, k.st.ms_logic);
       stats->ms_other = std::max(stats->ms_other, k.st.ms_other);
       stats->ms_fused = std::max(stats->ms_fused, k.st.ms_fused);
+    }
+    stats->ms_render_min = stats->ms_render_max = ranks[0].st.ms_total;
+    for (int r = 0; r < R; r++) {
+      if (n_cols[r] == 0) continue;
+      stats->ms_render_min = std::min(stats->ms_render_min, ranks[r].st.ms_total);
+      stats->ms_render_max = std::max(stats->ms_render_max, ranks[r].st.ms_total);
     }
     stats->ms_gather = std::chrono::duration<double, std::milli>(t_end - t_joined).count();
     stats->ms_total = std::chrono::duration<double, std::milli>(t_end - t_start).count();

@@ -25,7 +25,9 @@ def local_buffer(torch, W, H, world, tile_cols, device):
 
 
 class ColumnGather:
-    """Pre-allocated buffers and index tensors for gathering a W x H framebuffer."""
+    """Pre-allocated buffers and the index tensor for gathering a W x H framebuffer: the ranks'
+    packed blocks land side by side in one buffer, and one indexed copy (a single kernel on a
+    GPU) puts every image column in its place."""
 
     def __init__(self, torch, dist, W, H, rank, world, tile_cols, device, dst=0, always_collective=False):
         self.torch, self.dist = torch, dist
@@ -34,13 +36,18 @@ class ColumnGather:
         self.n_local = len(partition_columns(W, rank, world, tile_cols))
         self.is_dst = rank == dst
         if self.is_dst:
-            shape = (max_columns(W, world, tile_cols) * H, 3)
-            self.parts = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(world)]
-            self.index = [torch.from_numpy(partition_columns(W, r, world, tile_cols).astype(np.int64)).to(device)
-                          for r in range(world)]
+            cmax = max_columns(W, world, tile_cols)
+            self.flat = torch.zeros((world * cmax * H, 3), dtype=torch.float32, device=device)
+            self.parts = [self.flat[r * cmax * H: (r + 1) * cmax * H] for r in range(world)]
+            # image column i is local column c of rank r: row r * cmax + c of the gathered blocks
+            src = np.zeros(W, np.int64)
+            for r in range(world):
+                cols = partition_columns(W, r, world, tile_cols)
+                src[cols] = r * cmax + np.arange(len(cols))
+            self.src = torch.from_numpy(src).to(device)
             self.full = torch.zeros((W, H, 3), dtype=torch.float32, device=device)
         else:
-            self.parts = self.index = self.full = None
+            self.flat = self.parts = self.src = self.full = None
 
     def __call__(self, local):
         """local: this rank's packed columns (padded).  Returns the (W, H, 3) image on
@@ -52,9 +59,7 @@ class ColumnGather:
         self.dist.gather(local, self.parts, dst=self.dst)
         if not self.is_dst:
             return None
-        for r in range(self.world):
-            n = len(self.index[r])
-            self.full.index_copy_(0, self.index[r], self.parts[r][: n * self.H].view(n, self.H, 3))
+        self.torch.index_select(self.flat.view(-1, self.H, 3), 0, self.src, out=self.full)
         return self.full
 
 

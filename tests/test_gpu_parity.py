@@ -561,6 +561,14 @@ def test_host_api_render_and_ppm(rt, scenes, tmp_path):
     assert np.array_equal(body, want)
 
 
+def test_multi_device_render_reports_its_partitions_times(rt):
+    sg = rt.default_scene()
+    _, st = sg.render_multi(96, 64, 8, [0, 0, 0], seed=1)
+    assert st.n_devices == 3 and 0 < st.ms_render_min <= st.ms_render_max <= st.ms_total
+    _, st1 = sg.render(96, 64, 8, seed=1)
+    assert st1.ms_render_min == st1.ms_render_max == st1.ms_total
+
+
 def test_multi_device_render_after_the_scene_changed(rt):
     """render_multi caches one upload per device; a change of the scene (here: one node's box
     overwritten so that a wall triangle is no longer reached) must drop them, or the next render_multi
@@ -903,12 +911,19 @@ def test_bench_multi_rank_code_path_on_one_gpu(rt, scenes, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                        "--width", "96", "--height", "64", "--spp", "8", "--no-cpu-baseline", "--no-extras",
+                        "--width", "96", "--height", "64", "--spp", "8", "--no-cpu-baseline", "--big", "128x96x16",
                         "--rehearse-gather", "--dump-image", str(tmp_path / "img.npy")],
                        env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
+    # what a run on several GPUs needs to explain itself: per-rank render times, the gather's cost,
+    # the tile width, and the large configuration rendered by the same ranks
+    mg = line["multi_gpu"]
+    assert len(mg["per_rank_render_ms"]) == 1 and mg["render_ms_max"] >= mg["render_ms_min"] > 0
+    assert mg["imbalance_max_over_mean"] == 1.0 and mg["gather_ms"] >= 0 and mg["tile_cols"] == 8
+    big = line["extra"][0]
+    assert big["msamples_per_s"] > 0 and len(big["per_rank_render_ms"]) == 1 and "128x96 at 16 spp" in big["workload"]
     O, so, sg = scenes
     want, _ = sg.render(96, 64, 8, seed=0)
     got = np.load(tmp_path / "img.npy").reshape(-1, 3)
