@@ -329,7 +329,8 @@ int build_scene_arrays(rtr_scene *s, const rtr_scene_desc *d, bool info_fits, Bu
     HIP_TRY(hipMemcpyAsync(&flags, dflags.ptr, sizeof(flags), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
-  if (flags.errors) return fail(RTR_ERR_INVALID, "unreachable nodes in the tree");
+  for (const auto &k : kinds)
+    if (flags.errors & k.bit) return fail(RTR_ERR_INVALID, k.what);
   return RTR_OK;
 }
 

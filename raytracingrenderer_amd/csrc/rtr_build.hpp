@@ -9,9 +9,9 @@
 //   * a node's position in pre-order is the number of nodes visited before it = on the way
 //     from the root down to it, one per step, plus the whole left subtree whenever the step
 //     goes right.  In a tree whose inner nodes all have two children a subtree with L leaves
-//     has 2L - 1 nodes, so "leaves under every node" is all that has to be known: every leaf
-//     walks up to the root once and adds one to each ancestor (k_build_count), then every
-//     node walks up once and sums (k_build_place).  The same walk gives a leaf's number among
+//     has 2L - 1 nodes, so "leaves under every node" is all that has to be known: counts climb
+//     from the leaves, the second child to reach a node carrying the sum on (k_build_count), then
+//     every node walks up once and sums (k_build_place).  The same walk gives a leaf's number among
 //     the leaves.  Trees are at most 64 levels deep, so a walk is short.
 //   * skip link = position + 2L - 1; parent = position of the parent (k_build_parent).
 //
@@ -122,18 +122,30 @@ k_build_links(BuildInput in, BuildTemp tmp, BuildFlags *flags) {
   if (atomicCAS(&tmp.parent_old[r], -1, i) != -1) build_error(flags, kBuildTwoParents);
 }
 
-// every leaf adds itself to all its ancestors
+// Leaves under every node, bottom up: a leaf climbs with its count of one; at every node the first
+// child to arrive leaves its count and stops, the second takes the sum and climbs on -- one atomic
+// addition per arrival and no word that more than two threads touch (every leaf adding itself to
+// every ancestor put a million additions on the root's word alone).  The addition carries the
+// count in its low 31 bits and an arrival mark in the top bit: the first arrival finds zero, the
+// second finds the first one's count under a set top bit, and its own mark on top of that carries
+// out of the word, which is left holding the plain sum.
+// A node that only one child reaches (a cycle above it, a subtree the root does not reach) is
+// never completed: the count at the root then falls short, which the caller checks.
 __global__ void __launch_bounds__(kBuildBlock)
 k_build_count(BuildInput in, BuildTemp tmp, BuildFlags *flags) {
   const int i = blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= in.n_nodes) return;
   if (!(in.left[i] < 0 && in.right[i] < 0)) return;
   int c = i;
+  uint32_t count = 1u;
   for (int steps = 0; c != in.root; steps++) {
     const int p = tmp.parent_old[c];
     if (p < 0) return build_error(flags, kBuildUnreachable);
-    if (steps >= kMaxDepth - 1) return build_error(flags, kBuildTooDeep);  // or a cycle
-    atomicAdd(&tmp.leaves_under[p], 1u);
+    // (also what ends a climb round a cycle of nodes that name each other as children)
+    if (steps >= kMaxDepth - 1) return build_error(flags, kBuildTooDeep);
+    const uint32_t before = atomicAdd(&tmp.leaves_under[p], count | 0x80000000u);
+    if (before == 0u) return;
+    count += before & 0x7fffffffu;
     c = p;
   }
 }
@@ -158,8 +170,8 @@ k_build_place(BuildInput in, BuildTemp tmp, BuildOutput out, BuildFlags *flags) 
   int c = i;
   for (int steps = 0; c != in.root; steps++) {
     const int p = tmp.parent_old[c];
-    if (p < 0 || steps >= kMaxDepth) {  // not under the root: reported by its leaves, or here
-      build_error(flags, kBuildUnreachable);
+    if (p < 0 || steps >= kMaxDepth - 1) {  // not under the root, or 64 levels and more below it
+      build_error(flags, p < 0 ? kBuildUnreachable : kBuildTooDeep);
       tmp.place[i] = -1;
       return;
     }
