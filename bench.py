@@ -110,28 +110,16 @@ def timed_render(torch, scene, W, H, spp, dev, profile=True, **kw):
             "queue_rays": st.rays - st.samples // max(1, spp)}
 
 
-def extras(torch, rt, dev, seed):
-    """The other measurement inputs on one GPU, a few seconds each: the 2048 x 2048 image at
-    4096 spp, the specular / microfacet variant with max_depth 16 and continue probability
-    0.95, and the default scene plus a 1 M-triangle height field (closest-hit throughput
-    against the bytes its traversal reads, then a render)."""
-    from raytracingrenderer_amd import scenes
-    out = []
-    sg = rt.default_scene()
-    r = timed_render(torch, sg, 2048, 2048, 4096, dev, seed=seed)
-    r["workload"] = "default Cornell box, 2048x2048 at 4096 spp, one GPU"
-    out.append(r)
-    sg.close()
+# MI355X random-gather rates by where a table is served from (measured per-CU rates times 256 CUs):
+# a table that fits the 256 MiB Infinity Cache 7.4 - 8.6 TB/s, a table swept from HBM 6.0 - 6.1 TB/s
+GATHER_PEAK_INFINITY_CACHE_GBS = 8600.0
+GATHER_PEAK_HBM_GBS = 6100.0
 
-    sv = rt.HostScene.from_spec(scenes.variant_scene_spec())
-    r = timed_render(torch, sv, 784, 784, 1024, dev, seed=seed, max_depth=16, rr_prob=0.95)
-    r["workload"] = ("Cornell box with specular / microfacet spheres, max_depth 16, continue "
-                     "probability 0.95 (both knobs are extensions: the reference hard-codes 0.6 "
-                     "and has no depth cap), 784x784 at 1024 spp")
-    out.append(r)
-    sv.close()
 
-    n = 708
+def mesh_case(torch, rt, scenes, dev, seed, n, render):
+    """Default scene + an n x n jittered height field: scene build times, closest-hit throughput
+    of 2^24 incoherent rays against the bytes the reference's traversal names for them, and
+    (render=True) a 784 x 784 x 256 spp render."""
     t0 = time.perf_counter()
     spec = scenes.heightfield_spec(n)
     t1 = time.perf_counter()
@@ -142,6 +130,9 @@ def extras(torch, rt, dev, seed):
     sm.device_scene()                  # rtr_scene_create: copy, check and lay out on the device
     torch.cuda.synchronize()
     t3 = time.perf_counter()
+    n_tri = 2 * n * n
+    scene_mb = (2 * n_tri * 32 + n_tri * 64) / 1e6  # what the traversal reads: node records and leaf records
+    in_cache = scene_mb < 256 * 1.048576
     nr = 1 << 24
     org, d = scenes.interior_rays(nr, seed=5)
     o_t, d_t = torch.from_numpy(org).to(dev), torch.from_numpy(d).to(dev)
@@ -163,35 +154,67 @@ def extras(torch, rt, dev, seed):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / reps
     gbs = bytes_per_launch / (ms * 1e-3) / 1e9
-    rec = {"workload": "default scene + %dx%d jittered height field (%d triangles, 2 M tree nodes)"
-                       % (n, n, 2 * n * n),
+    peak = GATHER_PEAK_INFINITY_CACHE_GBS if in_cache else GATHER_PEAK_HBM_GBS
+    bound = ("l2-miss gather (scene in Infinity Cache)" if in_cache
+             else "hbm gather (scene larger than the Infinity Cache)")
+    rec = {"workload": "default scene + %dx%d jittered height field (%d triangles, %.1f M tree nodes, %d MB of node and leaf records)"
+                       % (n, n, n_tri, 2 * n_tri / 1e6, scene_mb),
            "scene_ms": {"mesh_arrays": (t1 - t0) * 1e3, "host_trees": (t2 - t1) * 1e3,
                         "host_flatten": (t2b - t2) * 1e3, "rtr_scene_create": (t3 - t2b) * 1e3},
            "trace": {"rays": nr, "mrays_per_s": nr / (ms * 1e-3) / 1e6, "ms_per_launch": ms,
                      "boxes_per_ray": boxes / nr, "triangles_per_ray": tris / nr,
                      "spheres_per_ray": sphs / nr,
-                     "roofline": {"kernel": "k_trace_api_stream", "bound": "hbm",
-                                  "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                     "roofline": {"kernel": "k_trace_api_stream", "bound": bound,
+                                  "achieved": gbs, "peak": peak, "unit": "GB/s",
+                                  "frac": gbs / peak, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "traffic": None,
                                   "bytes_per_ray": bytes_per_launch / nr,
                                   "note": "algorithmic bytes (32 B per box the reference tests, 48 B per "
                                           "triangle, 16 B per sphere, 36 B per ray in and out), counted "
                                           "on the device for these rays; launches timed with events on the "
-                                          "launch stream.  The 110 MB scene fits the 256 MB Infinity "
-                                          "Cache, so the bytes are served by L2 / Infinity Cache / HBM "
-                                          "together: the bound is the memory fabric, priced at the HBM peak"}}}
+                                          "launch stream.  Incoherent fetches of 32- and 64-byte records: "
+                                          "priced against the chip's measured random-gather rate from where "
+                                          "the scene is served (Infinity Cache 7.4 - 8.6 TB/s, HBM 6.0 - 6.1 "
+                                          "TB/s), not against the 8 TB/s streaming peak"}}}
     del o_t, d_t, prim, t
-    # (no per-kernel events here: they would keep the two streams of the loop from overlapping)
-    r = timed_render(torch, sm, 784, 784, 256, dev, profile=False, seed=seed)
-    # the render's rays are heavier than the isotropic test rays above: bytes counted per render
-    rb = 32.0 * r["boxes_tested"] + 48.0 * r["prims_tested"] + 36.0 * r["queue_rays"]
-    r["roofline"] = {"kernel": "k_trace_queue_stream (whole render: path logic, pool fill and drain included)",
-                     "bound": "hbm", "achieved": rb / (r["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                     "unit": "GB/s", "frac": rb / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                     "bytes_per_ray": rb / max(1, r["queue_rays"])}
-    rec["render_784x784_256spp"] = r
-    out.append(rec)
+    if render:
+        # (no per-kernel events here: they would keep the two streams of the loop from overlapping)
+        r = timed_render(torch, sm, 784, 784, 256, dev, profile=False, seed=seed)
+        # the render's rays are heavier than the isotropic test rays above: bytes counted per render
+        rb = 32.0 * r["boxes_tested"] + 48.0 * r["prims_tested"] + 36.0 * r["queue_rays"]
+        ach = rb / (r["ms"] * 1e-3) / 1e9
+        r["roofline"] = {"kernel": "k_trace_queue_stream (whole render: path logic, pool fill and drain included)",
+                         "bound": bound, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                         "frac_of_hbm_peak": ach / PEAK_HBM_GBS, "traffic": None,
+                         "bytes_per_ray": rb / max(1, r["queue_rays"])}
+        rec["render_784x784_256spp"] = r
     sm.close()
+    return rec
+
+
+def extras(torch, rt, dev, seed):
+    """The other measurement inputs on one GPU, a few seconds each: the 2048 x 2048 image at
+    4096 spp, the specular / microfacet variant with max_depth 16 and continue probability
+    0.95, and the default scene plus a height field of 1 M triangles (closest-hit throughput
+    against the bytes its traversal reads, then a render) and of 4.5 M triangles (closest hit only)."""
+    from raytracingrenderer_amd import scenes
+    out = []
+    sg = rt.default_scene()
+    r = timed_render(torch, sg, 2048, 2048, 4096, dev, seed=seed)
+    r["workload"] = "default Cornell box, 2048x2048 at 4096 spp, one GPU"
+    out.append(r)
+    sg.close()
+
+    sv = rt.HostScene.from_spec(scenes.variant_scene_spec())
+    r = timed_render(torch, sv, 784, 784, 1024, dev, seed=seed, max_depth=16, rr_prob=0.95)
+    r["workload"] = ("Cornell box with specular / microfacet spheres, max_depth 16, continue "
+                     "probability 0.95 (both knobs are extensions: the reference hard-codes 0.6 "
+                     "and has no depth cap), 784x784 at 1024 spp")
+    out.append(r)
+    sv.close()
+
+    out.append(mesh_case(torch, rt, scenes, dev, seed, 708, render=True))
+    # more than the 256 MiB Infinity Cache holds: what the same traversal reaches from HBM
+    out.append(mesh_case(torch, rt, scenes, dev, seed, 1500, render=False))
     return out
 
 

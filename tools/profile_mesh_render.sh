@@ -11,9 +11,17 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o mesh -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > $OUT/render.txt 2> $OUT/ktrace.log || { tail -5 $OUT/ktrace.log; exit 1; }
 timeout -s KILL 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > /dev/null 2> $OUT/pmc_fetch.log || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 timeout -s KILL 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > /dev/null 2> $OUT/pmc_write.log || { tail -5 $OUT/pmc_write.log; exit 1; }
+timeout -s KILL 250 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -o p -- python3 $R/tools/mesh_render_once.py ${2:-64} 1 ${3:-2} > /dev/null 2> $OUT/pmc_sq.log || { tail -5 $OUT/pmc_sq.log; exit 1; }
 python3 - <<PY
 import csv, glob, os, collections, json
 out = "$OUT"
+# vector-unit counters per kernel, summed over the program's dispatches
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("::")[-1]
+        sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
+json.dump({k: dict(v) for k, v in sq.items() if v.get("SQ_INSTS_VALU", 0) > 1e7}, open(os.path.join(out, "mesh_render_sq.json"), "w"), indent=1, sort_keys=True)
 # memory-side traffic per kernel over the whole program (warm-up render included):
 # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes
 tr = collections.defaultdict(lambda: {"read_bytes": 0.0, "write_bytes": 0.0, "dispatches": 0})
