@@ -130,7 +130,9 @@ struct rtr_scene {
   // photon emission: per-path counts of a batch, per-workgroup sums and offsets,
   // {photons in the batch, -}, number of paths the map took
   DevBuf<uint32_t> ph_counts, ph_paths_used;
-  DevBuf<unsigned long long> ph_sums, ph_offs, ph_total;
+  DevBuf<unsigned long long> ph_sums, ph_offs, ph_total, ph_first;
+  DevBuf<uint32_t> ph_wave_count;  // per wave of a batch, and the overflow flag after them
+  DevBuf<float4> ph_stage;  // photons of a batch before they are put in path order
   Workspace ws;
   // scratch for the host-pointer entry points
   DevBuf<float> io_f[5];
@@ -885,6 +887,7 @@ void rtr_scene_destroy(rtr_scene *s) {
   for (hipEvent_t e : s->trace_done)
     if (e) (void)hipEventDestroy(e);
   s->ph_counts.release(); s->ph_paths_used.release(); s->ph_sums.release(); s->ph_offs.release();
+  s->ph_first.release(); s->ph_wave_count.release(); s->ph_stage.release();
   s->ph_total.release();
   for (auto &b : s->io_f) b.release();
   for (auto &b : s->io_i) b.release();
@@ -1154,24 +1157,53 @@ int rtr_create_photon_map_device(rtr_scene *s, uint64_t photon_num, uint32_t see
     HIP_TRY(s->ph_sums.reserve(nb));
     HIP_TRY(s->ph_offs.reserve(nb));
     PhotonArgs a{seed, (uint32_t)paths, n_paths, filled, photon_num};
-    if (s->lds_geometry)
-      hipLaunchKernelGGL((k_photon_paths<true, false>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
-                         d_power, s->ph_paths_used.ptr);
-    else
-      hipLaunchKernelGGL((k_photon_paths<false, false>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
-                         d_power, s->ph_paths_used.ptr);
+    auto paths_pass = [&](int pass, PhotonStage stage) {
+      auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl, s->mats.ptr, s->ph_counts.ptr,
+                           s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi, d_power, s->ph_paths_used.ptr, stage);
+      };
+      if (s->lds_geometry) {
+        if (pass == kPhotonCount) launch(k_photon_paths<true, kPhotonCount>);
+        else if (pass == kPhotonWrite) launch(k_photon_paths<true, kPhotonWrite>);
+        else launch(k_photon_paths<true, kPhotonStage>);
+      } else {
+        if (pass == kPhotonCount) launch(k_photon_paths<false, kPhotonCount>);
+        else if (pass == kPhotonWrite) launch(k_photon_paths<false, kPhotonWrite>);
+        else launch(k_photon_paths<false, kPhotonStage>);
+      }
+    };
+    // One pass: the paths run once and stage their photons (every wave in room of its own), the
+    // counts are scanned, the photons move to their places.  A batch in which some wave ran out
+    // of room is run again the slow way (count, scan, run again and write).
+    const size_t n_waves = n_paths / 64;
+    // (RTR_PHOTON_WAVE_ROOM: a test's way to a batch that runs out of room)
+    static const unsigned room = [] {
+      const char *e = getenv("RTR_PHOTON_WAVE_ROOM");
+      const long v = e ? atol(e) : 0;
+      return v > 0 && v < (long)kPhotonWaveRoom ? (unsigned)v : kPhotonWaveRoom;
+    }();
+    HIP_TRY(s->ph_stage.reserve(3 * n_waves * room));
+    HIP_TRY(s->ph_first.reserve(n_paths));
+    HIP_TRY(s->ph_wave_count.reserve(n_waves + 1));
+    uint32_t *overflow = s->ph_wave_count.ptr + n_waves;
+    HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(uint32_t), st));
+    PhotonStage stage{room, s->ph_stage.ptr, s->ph_wave_count.ptr, overflow};
+    paths_pass(kPhotonStage, stage);
     hipLaunchKernelGGL(k_photon_scan, dim3(1), dim3(kBlock), 0, st, s->ph_sums.ptr, s->ph_offs.ptr, nb,
                        s->ph_total.ptr);
-    if (s->lds_geometry)
-      hipLaunchKernelGGL((k_photon_paths<true, true>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
-                         d_power, s->ph_paths_used.ptr);
-    else
-      hipLaunchKernelGGL((k_photon_paths<false, true>), dim3(nb), dim3(kBlock), 0, st, a, s->ds, s->dl,
-                         s->mats.ptr, s->ph_counts.ptr, s->ph_sums.ptr, s->ph_offs.ptr, d_pos, d_wi,
-                         d_power, s->ph_paths_used.ptr);
+    hipLaunchKernelGGL(k_photon_offsets, dim3(nb), dim3(kBlock), 0, st, a, s->ph_counts.ptr, s->ph_offs.ptr,
+                       s->ph_first.ptr, s->ph_paths_used.ptr);
+    hipLaunchKernelGGL(k_photon_scatter, dim3((unsigned)((n_waves * room + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, a, stage, s->ph_first.ptr, d_pos, d_wi, d_power);
+    uint32_t overflowed = 0;
+    HIP_TRY(hipMemcpyAsync(&overflowed, overflow, sizeof(overflowed), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (overflowed) {
+      paths_pass(kPhotonCount, stage);
+      hipLaunchKernelGGL(k_photon_scan, dim3(1), dim3(kBlock), 0, st, s->ph_sums.ptr, s->ph_offs.ptr, nb,
+                         s->ph_total.ptr);
+      paths_pass(kPhotonWrite, stage);
+    }
     HIP_TRY(hipGetLastError());
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, s->ph_total.ptr, sizeof(total), hipMemcpyDeviceToHost, st));

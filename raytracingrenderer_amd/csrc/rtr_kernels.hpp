@@ -1314,13 +1314,31 @@ struct PhotonArgs {
   unsigned long long limit;  // photon_num
 };
 
-template <bool kLds, bool kWrite>
+// kPass 0: count what every path stores; 1: run the same paths again and write (the two passes of
+// the fallback); 2: the usual way, one pass -- every photon goes to a staging array as it is found,
+// in whatever order the waves reach it, tagged with its path and its number within the path, and
+// k_photon_scatter moves it to its place once the paths' counts have been scanned.
+enum { kPhotonCount = 0, kPhotonWrite = 1, kPhotonStage = 2 };
+// Staging: every wave owns room for kPhotonWaveRoom photons (six per path; the default scene stores
+// 1.8) and fills it front to back -- positions come from a counter the wave keeps to itself, so no
+// memory round trip sits in the bounce loop.  A wave that runs out of room raises `overflow`: the
+// batch is then run again the slow way.
+constexpr unsigned kPhotonWaveRoom = 384;
+struct PhotonStage {
+  unsigned room;         // kPhotonWaveRoom (smaller in the test that drives a batch out of room)
+  float4 *records;       // per wave kPhotonWaveRoom x 3: {pos, bits(path in batch)} {wi, bits(number in path)} {power, -}
+  uint32_t *wave_count;  // photons each wave staged
+  uint32_t *overflow;
+};
+
+template <bool kLds, int kPass>
 __global__ void __launch_bounds__(kBlock)
 k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__restrict__ mats,
                uint32_t *__restrict__ counts, unsigned long long *__restrict__ block_sums,
                const unsigned long long *__restrict__ block_offs, float *__restrict__ pos3,
                float *__restrict__ wi3, float *__restrict__ power3,
-               unsigned int *__restrict__ paths_used) {
+               unsigned int *__restrict__ paths_used, PhotonStage stage) {
+  constexpr bool kWrite = kPass == kPhotonWrite;
   __shared__ typename WaveLds<kLds>::type wsh[kBlock / 64];
   __shared__ LdsScene lds;
   __shared__ unsigned s_cnt[kBlock];
@@ -1362,6 +1380,7 @@ k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     ppow = xyz(im.e_kind);
   }
   uint32_t k = 0, bounce = 0;
+  unsigned staged = 0;  // kPhotonStage: photons the wave has put into its room (wave-uniform)
   int max_deep = 64;
   while (__ballot(active)) {
     V3 wo = mk(0, 0, 1);
@@ -1386,6 +1405,8 @@ k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     }
     const V3 wn = unit(wo);
     const HitRec h = trace_any<kLds>(sc, lds, shoot, ppos, wo, wn, ws);
+    bool store = false;
+    V3 s_pos = mk(0, 0, 0), s_wi = s_pos, s_pow = s_pos;
     if (shoot) {
       bool go_on = false;
       if (h.leaf >= 0) {
@@ -1405,7 +1426,12 @@ k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
               wi3[q] = nw.x; wi3[q + 1] = nw.y; wi3[q + 2] = nw.z;
               power3[q] = npow.x; power3[q + 1] = npow.y; power3[q + 2] = npow.z;
             }
-            k++;
+            if (kPass == kPhotonStage) {
+              store = true;
+              s_pos = hp; s_wi = nw; s_pow = npow;
+            } else {
+              k++;
+            }
           }
           ppos = hp;
           pwi = nw;
@@ -1425,6 +1451,25 @@ k_photon_paths(PhotonArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         bounce++;
       }
     }
+    if (kPass == kPhotonStage) {
+      // the wave's photons of this bounce, appended to the wave's own room by rank in the ballot
+      const unsigned long long m = __ballot(store);
+      if (store) {
+        const unsigned at = staged + (unsigned)__popcll(m & lanes_below());
+        if (at < stage.room) {
+          float4 *rec = stage.records + 3 * ((size_t)(p >> 6) * stage.room + at);
+          rec[0] = pack(s_pos, p);
+          rec[1] = pack(s_wi, k);
+          rec[2] = pack(s_pow, 0u);
+        }
+        k++;
+      }
+      staged += (unsigned)__popcll(m);
+    }
+  }
+  if (kPass == kPhotonStage && lane_id() == 0) {
+    stage.wave_count[p >> 6] = staged < stage.room ? staged : stage.room;
+    if (staged > stage.room) *stage.overflow = 1u;
   }
   if (!kWrite) {
     if (valid) counts[p] = k;
@@ -1452,6 +1497,45 @@ k_photon_scan(const unsigned long long *__restrict__ block_sums, unsigned long l
     before += block_sums[b];
   }
   if (threadIdx.x == kBlock - 1) *total = before;
+}
+
+// Every path's first position in the map, from the paths' counts and the workgroups' offsets; the
+// path that stores photon number `limit` is the last one the reference starts.
+__global__ void __launch_bounds__(kBlock)
+k_photon_offsets(PhotonArgs a, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ block_offs,
+                 unsigned long long *__restrict__ path_first, unsigned int *__restrict__ paths_used) {
+  __shared__ unsigned s_cnt[kBlock];
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned mine = p < a.n_paths ? counts[p] : 0u;
+  s_cnt[threadIdx.x] = mine;
+  __syncthreads();
+  // inclusive scan over the workgroup
+  for (unsigned d = 1; d < kBlock; d <<= 1) {
+    const unsigned add = threadIdx.x >= d ? s_cnt[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_cnt[threadIdx.x] += add;
+    __syncthreads();
+  }
+  if (p >= a.n_paths) return;
+  const unsigned long long first = a.base + block_offs[blockIdx.x] + (s_cnt[threadIdx.x] - mine);
+  path_first[p] = first;
+  if (first < a.limit && first + mine >= a.limit) *paths_used = a.first_path + p + 1u;
+}
+
+// staged photons to their places: path order, and within a path the order they were found in
+__global__ void __launch_bounds__(kBlock)
+k_photon_scatter(PhotonArgs a, PhotonStage stage, const unsigned long long *__restrict__ path_first,
+                 float *__restrict__ pos3, float *__restrict__ wi3, float *__restrict__ power3) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned long long wave = i / stage.room;
+  if (wave >= (a.n_paths + 63u) / 64u || i % stage.room >= stage.wave_count[wave]) return;
+  const float4 r0 = stage.records[3 * i], r1 = stage.records[3 * i + 1], r2 = stage.records[3 * i + 2];
+  const unsigned long long at = path_first[wbits(r0)] + wbits(r1);
+  if (at >= a.limit) return;
+  const unsigned long long q = 3ull * at;
+  pos3[q] = r0.x; pos3[q + 1] = r0.y; pos3[q + 2] = r0.z;
+  wi3[q] = r1.x; wi3[q + 1] = r1.y; wi3[q + 2] = r1.z;
+  power3[q] = r2.x; power3[q + 1] = r2.y; power3[q + 2] = r2.z;
 }
 
 // ---- unit-level entry points used by the parity tests ----

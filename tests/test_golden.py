@@ -294,6 +294,31 @@ def test_gpu_photon_map(gsc):
 
 
 @pytest.mark.gpu
+def test_gpu_photon_map_when_the_staging_room_runs_out(gsc, tmp_path):
+    """The emission pass stages every wave's photons in room of a fixed size and redoes a batch
+    the slow way (count, scan, run again) when a wave runs out of it.  With room for one photon
+    per path (RTR_PHOTON_WAVE_ROOM=64, read when the library first needs it: hence a process of
+    its own) every batch takes that way; the map must be the same."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import raytracingrenderer_amd as rt; "
+            "sg = rt.default_scene(); p = sg.create_photon_map(60000, 3); "
+            "np.savez(%r, pos=p[0], wi=p[1], power=p[2], used=p[3])"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "ph.npz")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTR_PHOTON_WAVE_ROOM="64"),
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(tmp_path / "ph.npz")
+    O = Oracle()
+    so = O.default_scene()
+    O.set_math(so, portable=True)
+    want = O.create_photon_map(so, 60000, 3)
+    assert int(got["used"]) == want[3]
+    for k, b in zip(("pos", "wi", "power"), want[:3]):
+        assert got[k].shape == b.shape and _rays.same_bits(got[k], b).all(), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [128, 256])
 def test_gpu_converged_image_matches_reference(gsc, size):
     """>=4096 spp image tier: linear float buffers, RMSE <= 1.5 x the RMSE between two
