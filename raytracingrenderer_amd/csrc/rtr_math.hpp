@@ -24,7 +24,11 @@ RTR_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 RTR_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 RTR_DEV V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 RTR_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+#ifdef RTR_EXP_CHEAP_DIV  // development switch (wrong bits): what the IEEE vector / scalar divisions cost
+RTR_DEV V3 operator/(V3 a, float s) { const float y = __builtin_amdgcn_rcpf(s); return mk(a.x * y, a.y * y, a.z * y); }
+#else
 RTR_DEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+#endif
 // include/Vector.h:139-141 -- products summed left to right
 RTR_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // include/Vector.h:147-149

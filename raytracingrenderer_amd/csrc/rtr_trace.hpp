@@ -1254,6 +1254,16 @@ RTR_DEV float min3_abs(float a, float b, float c) {  // min(a, |b|, |c|)
   asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+RTR_DEV float min3_abs3(float a, float b, float c) {  // min(|a|, |b|, |c|)
+  float r;
+  asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+RTR_DEV float max3_abs3(float a, float b, float c) {  // max(|a|, |b|, |c|)
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 RTR_DEV float max3_abs(float a, float b, float c) {  // max(a, |b|, |c|)
   float r;
   asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -1530,9 +1540,13 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
                          n_hi <= 1099511627776.0f && n_tiny == 0u &&                           // 2^40
                          (a_fast || (reach_a | reach_b) == 0u);
   bool retrace_a = !(shared_ok && fabsf(ts_a) < inf), retrace_b = !(shared_ok && fabsf(ts_b) < inf);
+  // direction components of magnitude in [2^-20, 2]: what the mirrored pairs and the division-free
+  // box test below both ask of a ray
+  const bool dir_ok_a = min3_abs3(dn_a.x, dn_a.y, dn_a.z) >= kFastLo && max3_abs3(dn_a.x, dn_a.y, dn_a.z) <= 2.0f;
+  const bool dir_ok_b = min3_abs3(dn_b.x, dn_b.y, dn_b.z) >= kFastLo && max3_abs3(dn_b.x, dn_b.y, dn_b.z) <= 2.0f;
   if (has_pairs) {
-    retrace_a = retrace_a || !mirror_dir_ok(dn_a);
-    retrace_b = retrace_b || !mirror_dir_ok(dn_b);
+    retrace_a = retrace_a || !dir_ok_a;
+    retrace_b = retrace_b || !dir_ok_b;
   }
   HitPair out;
   {
@@ -1542,26 +1556,47 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
     out.node_a = ba.k >= 0 ? la.x : -1;
     out.node_b = bb.k >= 0 ? lb.x : -1;
   }
-  // both winners' boxes: the leaf's own box, or leaf to root (see trace_all); one ray after
-  // the other, so that only one test's quotients are in registers at a time
-  const bool leaf_only = sc.fast_planes != 0 && sc.nested_boxes != 0;
-  auto chain_ok = [&](int node, V3 d) {
-    const bool fast = sc.fast_planes != 0 && fast_ray(o, d);
-    // RN(1/d): a fast ray's direction components are within reciprocal_fast's range
-    V3 inv;
-    if (__ballot(!fast) == 0) inv = mk(reciprocal_fast(d.x), reciprocal_fast(d.y), reciprocal_fast(d.z));
-    else inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    bool ok = true;
-    while (node >= 0) {
-      const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
-      const bool pass = fast ? slab_fast(lo, hi, o, d, inv) : slab(lo, hi, o, d);
-      ok = ok && pass;
-      node = (leaf_only && fast) ? -1 : lds.parent[node];
-    }
-    return ok;
-  };
-  const bool ok_a = chain_ok(out.node_a, dn_a);
-  const bool ok_b = chain_ok(out.node_b, dn_b);
+  // Both winners' boxes (see trace_all).  Where the planes are in the division-free test's range
+  // and boxes are nested, the leaf's own box decides and the test is that one box by slab_fast;
+  // a ray outside its preconditions (a direction component outside [2^-20, 2], an origin component
+  // that is neither zero nor of magnitude in [2^-20, 2^20]) is re-traced.  Elsewhere: leaf to root,
+  // with the IEEE divisions when some lane needs them.
+  bool ok_a, ok_b;
+  if (sc.fast_planes != 0 && sc.nested_boxes != 0) {
+    // origin: twice the magnitude's bit pattern less one wraps a zero to the top, so the least of
+    // the three is at least 2 * bits(2^-20) - 1 unless some component is tiny and not zero
+    const uint32_t ox = __float_as_uint(o.x), oy = __float_as_uint(o.y), oz = __float_as_uint(o.z);
+    const bool o_ok = min3_u32(ox + ox - 1u, oy + oy - 1u, oz + oz - 1u) >= 2u * 0x35800000u - 1u &&
+                      max3_abs3(o.x, o.y, o.z) <= kFastHi;
+    retrace_a = retrace_a || !(o_ok && dir_ok_a);
+    retrace_b = retrace_b || !(o_ok && dir_ok_b);
+    auto leaf_box_ok = [&](int node, V3 d) {
+      const V3 inv = mk(reciprocal_fast(d.x), reciprocal_fast(d.y), reciprocal_fast(d.z));
+      const int at = node >= 0 ? node : 0;
+      const float4 lo = lds.nodes[2 * at], hi = lds.nodes[2 * at + 1];
+      return slab_fast(lo, hi, o, d, inv) || node < 0;
+    };
+    ok_a = leaf_box_ok(out.node_a, dn_a);
+    ok_b = leaf_box_ok(out.node_b, dn_b);
+  } else {
+    auto chain_ok = [&](int node, V3 d) {
+      const bool fast = sc.fast_planes != 0 && fast_ray(o, d);
+      // RN(1/d): a fast ray's direction components are within reciprocal_fast's range
+      V3 inv;
+      if (__ballot(!fast) == 0) inv = mk(reciprocal_fast(d.x), reciprocal_fast(d.y), reciprocal_fast(d.z));
+      else inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      bool ok = true;
+      while (node >= 0) {
+        const float4 lo = lds.nodes[2 * node], hi = lds.nodes[2 * node + 1];
+        const bool pass = fast ? slab_fast(lo, hi, o, d, inv) : slab(lo, hi, o, d);
+        ok = ok && pass;
+        node = lds.parent[node];
+      }
+      return ok;
+    };
+    ok_a = chain_ok(out.node_a, dn_a);
+    ok_b = chain_ok(out.node_b, dn_b);
+  }
   unsigned long long need_a = __ballot(valid_a && (retrace_a || !ok_a));
   unsigned long long need_b = __ballot(valid_b && (retrace_b || !ok_b));
   RTR_STAT(6, __popcll(need_a) + __popcll(need_b));
