@@ -938,6 +938,8 @@ int rtr_self_test(int device, uint64_t *mismatches) {
       hipLaunchKernelGGL(k_selftest_sqrt, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, lo + done,
                          count, d_bad);
     }
+    hipLaunchKernelGGL(k_selftest_unit_near, dim3((1u << 20) / kBlock), dim3(kBlock), 0, nullptr, kNearOneLo,
+                       kNearOneHi, d_bad);
     for (uint32_t round = 0; round < 16; round++)  // 2^32 vectors
       hipLaunchKernelGGL(k_selftest_unit, dim3(1u << 20), dim3(kBlock), 0, nullptr, round * 7919u + 1u, d_bad);
     e = hipGetLastError();

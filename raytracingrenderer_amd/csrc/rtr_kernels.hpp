@@ -330,6 +330,30 @@ k_selftest_unit(uint32_t round, unsigned long long *__restrict__ mismatches) {
   if (differ(got.x, want.x) || differ(got.y, want.y) || differ(got.z, want.z)) atomicAdd(mismatches, 1ull);
 }
 
+// unit_near's two steps against sqrtf and the IEEE quotient, exhaustively: every sum of squares of
+// its window (s_lo ... s_hi), and for each the quotient of every float of magnitude zero or in
+// [2^-100, 2] by the length.  Thread i takes the numerators i, i + stride, ...
+__global__ void __launch_bounds__(kBlock)
+k_selftest_unit_near(uint32_t s_lo, uint32_t s_hi, unsigned long long *__restrict__ mismatches) {
+  const uint32_t tid = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  unsigned bad = 0;
+  for (uint32_t sb = s_lo; sb <= s_hi; sb++) {
+    const float s = __uint_as_float(sb);
+    const float l = near_one_sqrt(s);
+    if (__float_as_uint(l) != __float_as_uint(sqrtf(s))) bad++;
+    const NearOne d(l);
+    // 2^32 / (grid size) numerators per thread; the launch has 2^20 threads
+    for (uint32_t k = 0; k < 4096u; k++) {
+      const uint32_t au = k * (1u << 20) + tid;
+      const uint32_t mag = au & 0x7fffffffu;
+      if (mag != 0u && (mag < 0x0d800000u || mag > 0x40000000u)) continue;  // tiny and not zero, or above 2
+      const float a = __uint_as_float(au);
+      if (__float_as_uint(d.quotient(a)) != __float_as_uint(a / l)) bad++;
+    }
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // ---- the algorithmic work of a ray batch ----
 // What the reference's traversal does for each ray, counted: boxes tested (every node the
 // recursion of src/BVH.cpp:66-80 enters), and triangles / spheres tested (leaves whose box
@@ -704,7 +728,8 @@ template <bool kUnitWi = false, class Tab>
 RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi, V3 beta,
                           uint32_t mat, uint32_t gpix, uint32_t k, uint32_t depth, Emit &e) {
   DeviceMaterial dm = T.mat(mat);
-  const V3 ui = kUnitWi ? wi : unit(wi), un = unit(N);  // shared by the two evaluations below
+  // (N is the normalised normal of the hit: its second normalisation takes the short way)
+  const V3 ui = kUnitWi ? wi : unit(wi), un = unit_near(N);  // shared by the two evaluations below
   VertexStream rng(a.seed, gpix, k, depth);
   LightSample ls;
   sample_light(T, rng, ls);
@@ -714,9 +739,9 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi
   e.light_pdf = ls.pdf;
   if (ls.pdf > 0) {
     V3 l = unit(ls.pos - pos);
-    V3 l2 = unit(l);
+    V3 l2 = unit_near(l);
     V3 Le = xyz(T.light_le(ls.light));
-    e.weight = Le * mat_eval_units(dm, ui, l2, un) * dot(N, l2) * dot(unit(ls.nrm), -l2);
+    e.weight = Le * mat_eval_units(dm, ui, l2, un) * dot(N, l2) * dot(unit_near(ls.nrm), -l2);
     e.l = l;
     e.ln = l2;
     e.has_shadow = true;
@@ -731,8 +756,8 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi
       wo = mat_sample_uv(N, u1, u2);
     }
     float pdf = mat_pdf(dm);
-    V3 w1 = unit(wo);
-    e.wn = unit(w1);
+    V3 w1 = unit_near(wo);  // a sampled or mirrored direction: of unit length up to rounding
+    e.wn = unit_near(w1);
     e.beta_next = beta * mat_eval_units(dm, ui, e.wn, un, e.uo_ext) * dot(N, w1) / pdf / a.rr;
     e.w1 = w1;
     e.has_ext = true;
@@ -1246,7 +1271,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
           hit_point_any<kLds>(sc, lds, he, pos, wn, hp, hn);
           beta = e.beta_next;
           wi = -e.uo_ext;
-          N = unit(hn);
+          N = unit_near(hn);  // a stored face normal or a sphere's normalised radius
           pos = hp;
           mat = (uint32_t)m2;
           depth++;

@@ -107,6 +107,44 @@ RTR_DEV V3 unit(V3 a) {
   const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);
 }
+// unit() of a vector that is a normalised vector already, up to rounding -- most of what the
+// reference normalises: it normalises the results of its own normalisations again (a ray's direction
+// by the ray's maker, by Bound3::intersect and by Material::eval; a normal by the primitive, by
+// Render::pathTracing and by Material::eval).  When the sum of squares s lies within a few dozen
+// ulps of one (kNearOneLo ... kNearOneHi, checked for the wave; else unit()):
+//   * RN(sqrt(s)) is (bits(s) >> 1) + 0x1fc00000: the bit pattern halved and re-biased is exact
+//     on that window;
+//   * a / l for l = 1 + e that close to one: q0 = RN(a - a e), its exact residual r = a - l q0,
+//     and q = RN(q0 + r y) with y = RN(1 - e (1 + 2^-20)), a reciprocal of l rounded away from the
+//     tie that l = 1 - 2^-24 would otherwise meet.  The numerator's sign is put back for a = -0.
+// Both are compared with sqrtf and the IEEE quotient for EVERY s of the window and every
+// numerator a float can be (zero, or of magnitude in [2^-100, 2]) by rtr_self_test -- the
+// window is small enough for that, which is why no rounding argument is needed here.  Components
+// that are tiny and not zero (below 2^-60, as in unit()) take unit().
+constexpr uint32_t kNearOneLo = 0x3f7ffff0u, kNearOneHi = 0x3f800008u;  // 1 - 2^-20 ... 1 + 2^-20
+RTR_DEV float near_one_sqrt(float s) { return __uint_as_float((__float_as_uint(s) >> 1) + 0x1fc00000u); }
+struct NearOne {
+  float l, e, y;
+  RTR_DEV explicit NearOne(float len) : l(len), e(len - 1.0f), y(__builtin_fmaf(-(len - 1.0f), 1.00000095367431640625f, 1.0f)) {}
+  RTR_DEV float quotient(float a) const {
+    const float q0 = __builtin_fmaf(-a, e, a);
+    const float r = __builtin_fmaf(-l, q0, a);
+    const float q = __builtin_fmaf(r, y, q0);
+    return __uint_as_float((__float_as_uint(q) & 0x7fffffffu) | (__float_as_uint(a) & 0x80000000u));
+  }
+};
+RTR_DEV V3 unit_near(V3 a) {
+  const float s = a.x * a.x + a.y * a.y + a.z * a.z;
+#ifdef RTR_EXP_CHEAP_UNIT
+  return unit(a);
+#endif
+  const uint32_t bx = __float_as_uint(a.x), by = __float_as_uint(a.y), bz = __float_as_uint(a.z);
+  const uint32_t least = min3_u32(bx + bx - 1u, by + by - 1u, bz + bz - 1u);
+  const bool bad = least < 2u * 0x21800000u - 1u || __float_as_uint(s) - kNearOneLo > kNearOneHi - kNearOneLo;
+  if (__ballot(bad) != 0) return unit(a);
+  const NearOne d(near_one_sqrt(s));
+  return mk(d.quotient(a.x), d.quotient(a.y), d.quotient(a.z));
+}
 // every component of unit((1, 1, 1)): 1 / RN(sqrt(3)) = 0x3f13cd3a
 constexpr float kUnitOfOnes = 0.5773502588272095f;
 // `disLen >= -1e-3 && disLen <= 1e-3` (src/Render.cpp:97-98) with disLen = |v| an fp32 length

@@ -91,7 +91,7 @@ RTR_DEV float fresnel_kr(V3 I, V3 N, float ior) {
 RTR_DEV float ggx_d(float roughness, V3 N, V3 H) {
   float a = roughness * roughness;
   float a2 = a * a;
-  float nh = maxf(dot(unit(N), unit(H)), 0.0f);
+  float nh = maxf(dot(unit_near(N), unit_near(H)), 0.0f);  // both come out of a normalisation
   float nh2 = nh * nh;
   float den = (float)((double)nh2 * ((double)a2 - 1.0) + 1.0);
   den = (float)(kPi * (double)den * (double)den);
@@ -119,7 +119,7 @@ RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un, V3 &uo) 
   if (kind == 2) kind = 0;
 #endif
   V3 kd = xyz(m.kd_ior);
-  uo = unit(wo);  // handed back: the next vertex's unit(wi) is its negation
+  uo = unit_near(wo);  // (callers pass a normalised direction) handed back: the next vertex's unit(wi) is its negation
   if (kind == 0) {
     float c = dot(uo, un);
     float f = c > 0.0f ? (float)(1.0f / kPi) : 0.0f;
