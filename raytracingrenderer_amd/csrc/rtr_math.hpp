@@ -121,7 +121,7 @@ RTR_DEV V3 unit(V3 a) {
 // numerator a float can be (zero, or of magnitude in [2^-100, 2]) by rtr_self_test -- the
 // window is small enough for that, which is why no rounding argument is needed here.  Components
 // that are tiny and not zero (below 2^-60, as in unit()) take unit().
-constexpr uint32_t kNearOneLo = 0x3f7ffff0u, kNearOneHi = 0x3f800008u;  // 1 - 2^-20 ... 1 + 2^-20
+constexpr uint32_t kNearOneLo = 0x3f7fffc0u, kNearOneHi = 0x3f800020u;  // 1 - 2^-18 ... 1 + 2^-18
 RTR_DEV float near_one_sqrt(float s) { return __uint_as_float((__float_as_uint(s) >> 1) + 0x1fc00000u); }
 struct NearOne {
   float l, e, y;

@@ -260,22 +260,18 @@ RTR_DEV f32x2 div_corrected2(f32x2 a, float d, float y) {
   return __builtin_elementwise_fma(r, yy, q);
 }
 
-// RN(1/d) without the range handling of an IEEE division.  hipcc expands 1.0f / d into
-// v_div_scale (twice), v_rcp, six fma steps, v_div_fmas and v_div_fixup; for a normal d
-// that is neither tiny nor huge the scaling steps scale by one and the fix-up passes the
-// quotient through, so the six fma steps on their own give the same bits:
-//   y0 = rcp(d); y1 = y0 + (1 - d y0) y0; q1 = y1 + (1 - d y1) y1; q = q1 + (1 - d q1) y1.
-// Precondition |d| in [2^-60, 2^60] (reciprocal_operand_fast); the self-test entry point
-// compares it with 1.0f / d for every float.
+// RN(1/d) without an IEEE division.  hipcc expands 1.0f / d into v_div_scale (twice), v_rcp, six
+// fma steps, v_div_fmas and v_div_fixup.  The hardware's estimate is good to one ulp, and ONE
+// Newton step in fused arithmetic, y1 = y0 + (1 - d y0) y0, already lands on the correctly rounded
+// reciprocal of every float whose magnitude is in [2^-60, 2^60] (reciprocal_operand_fast): not
+// argued but checked -- the self-test entry point compares it with 1.0f / d for every float.
 RTR_DEV bool reciprocal_operand_fast(float d) {
   const float m = fabsf(d);
   return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // 2^-60, 2^60
 }
 RTR_DEV float reciprocal_fast(float d) {
   const float y0 = __builtin_amdgcn_rcpf(d);
-  const float y1 = __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
-  const float q1 = __builtin_fmaf(__builtin_fmaf(-d, y1, 1.0f), y1, y1);
-  return __builtin_fmaf(__builtin_fmaf(-d, q1, 1.0f), y1, q1);
+  return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
 }
 // 1.0f / d, by the short sequence when every lane of the wave may take it
 RTR_DEV f32x2 reciprocal_pair(f32x2 d) {
