@@ -37,15 +37,14 @@ RTR_DEV V3 cross(V3 a, V3 b) {
 }
 // include/Vector.h:79
 RTR_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-// RN(sqrt(s)) for a normal s in [2^-100, 2^100] without the range handling of sqrtf:
-// Markstein's sequence from the reciprocal square root y (g -> sqrt(s), h -> 1 / (2 sqrt(s)),
-// one coupled refinement, one correction of g by its exact residual).  rtr_self_test compares
-// it with sqrtf for every float of that range.
+// RN(sqrt(s)) for a normal s in [2^-100, 2^100] without the range handling of sqrtf: from the
+// hardware's reciprocal square root y, g = s y is the root to about an ulp and h = y / 2 the
+// factor that turns the exact residual s - g g into its correction.  That one correction is the
+// correctly rounded root for every float of the range: rtr_self_test compares it with sqrtf for
+// all of them (Markstein's longer sequence, with a coupled refinement of g and h first, gave the
+// same bits everywhere).
 RTR_DEV float sqrt_from_rsq(float s, float y) {
-  float g = s * y, h = 0.5f * y;
-  const float r = __builtin_fmaf(-h, g, 0.5f);
-  g = __builtin_fmaf(g, r, g);
-  h = __builtin_fmaf(h, r, h);
+  const float g = s * y, h = 0.5f * y;
   const float d = __builtin_fmaf(-g, g, s);
   return __builtin_fmaf(d, h, g);
 }
