@@ -29,7 +29,7 @@ res["rays_per_launch"] = 1 << 24
 if res.get("SQ_INSTS_VALU"):
     # SQ_ACTIVE_INST_VALU counts quad-cycles; lanes active per vector instruction out of 64
     res["valu_active_cycles_per_instruction"] = 4.0 * res["SQ_ACTIVE_INST_VALU"] / res["SQ_INSTS_VALU"]
-    res["lanes_active_per_valu_instruction"] = res["SQ_THREAD_CYCLES_VALU"] / (4.0 * res["SQ_ACTIVE_INST_VALU"]) if res.get("SQ_ACTIVE_INST_VALU") else None
+    res["lanes_active_frac"] = res["SQ_THREAD_CYCLES_VALU"] / (64.0 * res["SQ_INSTS_VALU"])
     res["valu_instructions_per_ray"] = res["SQ_INSTS_VALU"] / res["rays_per_launch"]
 json.dump(res, open(os.path.join(out, "mesh_pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(out, "ktrace", "**", "*kernel_stats.csv"), recursive=True):
