@@ -197,7 +197,10 @@ int rtr_device_count(int *n);
  * square root of a normalisation with sqrtf for every float in [2^-100, 2^100), and the
  * normalisation's quotients by way of a double-precision reciprocal with the IEEE quotients
  * on 2^32 vectors built to be hard (components next to midpoint quotients, zeros, denormals,
- * lengths outside the short path's range).
+ * lengths outside the short path's range); the closed-form normalisation of vectors already of
+ * unit length on every case of its window; colour / scalar / scalar by reciprocals and one
+ * residual correction with the six IEEE divisions on 2^30 colours, zeros of either sign and
+ * operands outside its range included.
  * *mismatches = number of differing results; anything but 0 means this toolchain or
  * device does not reproduce the reference's arithmetic and results are not to be trusted.
  */

@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE.  Checks the claim the traversal kernels rely on: for fp32
  * a, d inside the stated ranges, with y = RN(1/d),
- *   q0 = a*y; r0 = fma(-d,q0,a); q1 = fma(r0,y,q0); r1 = fma(-d,q1,a); q2 = fma(r1,y,q1)
+ *   q0 = a*y; r = fma(-d,q0,a); q = fma(r,y,q0)
  * equals the IEEE quotient a/d bit for bit (zeros compare equal regardless of sign).
  * Prints the number of mismatches; exit status 0 iff none.
  *   usage: check_division [samples] [seed]
@@ -26,8 +26,6 @@ static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float corrected(float a, float d, float y) {
   float q = a * y;
   float r = fmaf(-d, q, a);
-  q = fmaf(r, y, q);
-  r = fmaf(-d, q, a);
   return fmaf(r, y, q);
 }
 

@@ -942,6 +942,8 @@ int rtr_self_test(int device, uint64_t *mismatches) {
                        kNearOneHi, d_bad);
     for (uint32_t round = 0; round < 16; round++)  // 2^32 vectors
       hipLaunchKernelGGL(k_selftest_unit, dim3(1u << 20), dim3(kBlock), 0, nullptr, round * 7919u + 1u, d_bad);
+    for (uint32_t round = 0; round < 4; round++)  // 2^30 colours
+      hipLaunchKernelGGL(k_selftest_div_div, dim3(1u << 20), dim3(kBlock), 0, nullptr, round * 104729u + 3u, d_bad);
     e = hipGetLastError();
   }
   unsigned long long bad = 0;

@@ -354,6 +354,37 @@ k_selftest_unit_near(uint32_t s_lo, uint32_t s_hi, unsigned long long *__restric
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// div_div against the six IEEE divisions it stands for: colours with components of either sign
+// and zeros of either sign over the short way's whole range of exponents, divisors over theirs;
+// and, by workgroup, what must send the wave to the IEEE divisions instead -- a tiny component, a
+// huge or infinite one, a divisor outside [2^-20, 2^20].  (div_corrected by itself was compared
+// with the IEEE quotient for every pair of significands: tools/ubench/exact_division.hip.)
+__global__ void __launch_bounds__(kBlock)
+k_selftest_div_div(uint32_t round, unsigned long long *__restrict__ mismatches) {
+  const uint32_t id = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const uint32_t r0 = selftest_mix(id * 2654435761u + round), r1 = selftest_mix(r0 + 0x9e3779b9u),
+                 r2 = selftest_mix(r1 ^ round), r3 = selftest_mix(r2 + id), r4 = selftest_mix(r3 ^ 0x85ebca6bu),
+                 r5 = selftest_mix(r4 + round);
+  const uint32_t kind = blockIdx.x & 7u;
+  auto number = [](uint32_t r, int e_lo, int e_hi) {  // random sign and significand, exponent in [e_lo, e_hi]
+    const int e = e_lo + (int)((r >> 24) % (uint32_t)(e_hi - e_lo + 1));
+    return __uint_as_float((r & 0x807fffffu) | ((uint32_t)(127 + e) << 23));
+  };
+  V3 x = mk(number(r0, -60, 59), number(r1, -60, 59), number(r2, -60, 59));
+  float d1 = fabsf(number(r3, -20, 19)), d2 = fabsf(number(r4, -20, 19));
+  if (kind == 1) x.y = (r5 & 1u) ? 0.0f : -0.0f;
+  if (kind == 2) { x.x = -0.0f; x.y = 0.0f; x.z = (r5 & 2u) ? 0.0f : -0.0f; }
+  if (kind == 3) { d1 = (r5 & 1u) ? 9.5367431640625e-07f : 1048576.0f; d2 = (r5 & 2u) ? 9.5367431640625e-07f : 1048576.0f; }
+  if (kind == 4) x.z = __uint_as_float(r5 & 0x807fffffu);                   // a denormal or zero component
+  if (kind == 5) x.x = (r5 & 1u) ? __int_as_float(0x7f800000) : 3.0e30f;    // infinite or huge
+  if (kind == 6) d1 = fabsf(number(r3, (r5 & 1u) ? -60 : 21, (r5 & 1u) ? -21 : 60));
+  if (kind == 7) x = mk(number(r0, -60, -50), number(r1, 50, 59), number(r2, -60, 59));  // the corners of the range
+  const V3 got = div_div(x, d1, d2);
+  const V3 want = mk(x.x / d1 / d2, x.y / d1 / d2, x.z / d1 / d2);
+  auto differ = [](float g, float w) { return __float_as_uint(g) != __float_as_uint(w) && !(g != g && w != w); };
+  if (differ(got.x, want.x) || differ(got.y, want.y) || differ(got.z, want.z)) atomicAdd(mismatches, 1ull);
+}
+
 // ---- the algorithmic work of a ray batch ----
 // What the reference's traversal does for each ray, counted: boxes tested (every node the
 // recursion of src/BVH.cpp:66-80 enters), and triangles / spheres tested (leaves whose box
@@ -758,7 +789,7 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi
     float pdf = mat_pdf(dm);
     V3 w1 = unit_near(wo);  // a sampled or mirrored direction: of unit length up to rounding
     e.wn = unit_near(w1);
-    e.beta_next = beta * mat_eval_units(dm, ui, e.wn, un, e.uo_ext) * dot(N, w1) / pdf / a.rr;
+    e.beta_next = div_div(beta * mat_eval_units(dm, ui, e.wn, un, e.uo_ext) * dot(N, w1), pdf, a.rr);
     e.w1 = w1;
     e.has_ext = true;
   } else {
@@ -808,7 +839,7 @@ k_logic(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMaterial *__re
       // which fails the distance test like the reference's `testInter.hit` does.
       if (flags & kHasShadow) {
         if (near_light(xyz(hs4) - xyz(h4))) {
-          V3 term = xyz(g4) / (hs4.w * hs4.w) / g4.w;
+          V3 term = div_div(xyz(g4), hs4.w * hs4.w, g4.w);
           Lp = Lp + beta * term;
         }
       }
@@ -1249,7 +1280,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
         V3 hp, hn;
         hit_point_any<kLds>(sc, lds, hs, pos, ln, hp, hn);
         if (near_light(hp - e.light_pos)) {
-          V3 term = e.weight / (hs.t * hs.t) / e.light_pdf;
+          V3 term = div_div(e.weight, hs.t * hs.t, e.light_pdf);
           const V3 add = beta * term;
           if constexpr (kLds) {
             us.Lp[0][tid] = us.Lp[0][tid] + add.x;

@@ -222,15 +222,16 @@ RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
 
 // Bound3::intersect without IEEE division instructions, same boolean.
 //
-// The reference divides six times per node and an IEEE fp32 division is about
-// ten instructions on CDNA.  With y = RN(1/d) formed once per ray and axis, each
-// quotient is rebuilt exactly by two residual corrections (Markstein):
-//   q0 = RN(a*y); r0 = fma(-d,q0,a); q1 = fma(r0,y,q0)   -> q1 within 1 ulp of a/d
-//   r1 = fma(-d,q1,a) (exact);       q2 = fma(r1,y,q1)   -> q2 = RN(a/d)
-// q2 is the correctly rounded quotient whenever y is the correctly rounded
-// reciprocal and nothing under- or overflows on the way, so min/max of the six
-// q2 and the final compare give the reference's result bit for bit.  The fma
-// calls are explicit; contraction stays off for everything else.
+// The reference divides six times per node and an IEEE fp32 division costs as much as
+// seventeen plain instructions on gfx950.  With y = RN(1/d) formed once per ray and axis,
+// each quotient is rebuilt by ONE residual correction:
+//   q0 = RN(a*y); r = fma(-d, q0, a) (exact); q = fma(r, y, q0)  =  RN(a/d).
+// That this is the correctly rounded quotient whenever y is the correctly rounded reciprocal
+// and nothing under- or overflows on the way is not argued here but was checked for every pair
+// of significands there is -- 2^46 pairs, tools/ubench/exact_division.hip, no mismatch
+// (rounding is symmetric in sign and, away from under- and overflow, sees significands only) --
+// so min/max of the six quotients and the final compare give the reference's result bit for
+// bit.  The fma calls are explicit; contraction stays off for everything else.
 //
 // Preconditions (else the IEEE-division test above is used): direction
 // components finite with magnitude in [2^-20, 2]; origin components and box planes
@@ -240,10 +241,8 @@ RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
 // (A zero quotient may come out as +0 where IEEE gives -0; the two compare equal in
 // every min, max and <= of the test, so its boolean is unaffected.)
 RTR_DEV float div_corrected(float a, float d, float y) {
-  float q = a * y;
-  float r = __builtin_fmaf(-d, q, a);
-  q = __builtin_fmaf(r, y, q);
-  r = __builtin_fmaf(-d, q, a);
+  const float q = a * y;
+  const float r = __builtin_fmaf(-d, q, a);
   return __builtin_fmaf(r, y, q);
 }
 
@@ -253,10 +252,8 @@ RTR_DEV float div_corrected(float a, float d, float y) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 RTR_DEV f32x2 div_corrected2(f32x2 a, float d, float y) {
   const f32x2 yy = {y, y}, nd = {-d, -d};
-  f32x2 q = a * yy;
-  f32x2 r = __builtin_elementwise_fma(nd, q, a);
-  q = __builtin_elementwise_fma(r, yy, q);
-  r = __builtin_elementwise_fma(nd, q, a);
+  const f32x2 q = a * yy;
+  const f32x2 r = __builtin_elementwise_fma(nd, q, a);
   return __builtin_elementwise_fma(r, yy, q);
 }
 
@@ -1046,7 +1043,7 @@ RTR_DEV HitRec trace_all(const DeviceScene &sc, const LdsScene &lds, bool valid,
   // per-ray invariants of src/Sphere.cpp:10-14
   const float qa = dn.x * dn.x + dn.y * dn.y + dn.z * dn.z;
   const float qa4 = 4 * qa;
-  // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
+  // n / qa by one fma correction of n * RN(1/qa) (div_corrected) is the IEEE quotient
   // when qa is in [0.5, 2] and |n| is in [2^-40, 2^40]
   const bool a_fast = qa >= 0.5f && qa <= 2.0f;
   const float ya = 1.0f / qa;
@@ -1185,10 +1182,8 @@ RTR_DEV V3x2 cross(V3x2 a, V3x2 b) {
 }
 RTR_DEV f32x2 div_corrected_pairs(f32x2 a, f32x2 d, f32x2 y) {
   const f32x2 nd = -d;
-  f32x2 q = a * y;
-  f32x2 r = __builtin_elementwise_fma(nd, q, a);
-  q = __builtin_elementwise_fma(r, y, q);
-  r = __builtin_elementwise_fma(nd, q, a);
+  const f32x2 q = a * y;
+  const f32x2 r = __builtin_elementwise_fma(nd, q, a);
   return __builtin_elementwise_fma(r, y, q);
 }
 
@@ -1276,6 +1271,36 @@ RTR_DEV uint32_t opaque(uint32_t v) {
   return v;
 }
 
+// colour / d1 / d2 with two positive scalars (src/Render.cpp:104: Le f cos cos' / dis^2 / pdf;
+// :125: f cos / pdf / P_RR): six IEEE divisions at the price of seventeen plain instructions
+// each.  The short way -- RN(1 / d) by reciprocal_fast, each quotient by div_corrected -- is
+// taken when, for every lane of the wave, both divisors are in [2^-20, 2^20] and every
+// component is zero or of magnitude in [2^-60, 2^60]: then the first quotients are zero or in
+// [2^-80, 2^80], the second ones in [2^-100, 2^100], and no product or residual leaves the normal
+// range.  Zero components are common (a light below the horizon of the surface) and of either
+// sign; div_corrected turns -0 into +0, so the numerator's sign is put back (the divisors
+// are positive: the quotient's sign is the numerator's).  A NaN component passes the guard unseen
+// by the maximum and comes out as a NaN either way.
+RTR_DEV V3 div_div(V3 x, float d1, float d2) {
+#ifndef RTR_EXP_IEEE_COLOUR_DIV
+  const uint32_t bx = __float_as_uint(x.x), by = __float_as_uint(x.y), bz = __float_as_uint(x.z);
+  // twice the magnitude's bit pattern less one wraps a zero to the top (see unit())
+  const uint32_t least = min3_u32(bx + bx - 1u, by + by - 1u, bz + bz - 1u);
+  const float most = max3_abs3(x.x, x.y, x.z);
+  const uint32_t lo = 0x35800000u, span = 0x49800000u - 0x35800000u;  // 2^-20 ... 2^20; negative numbers and NaNs lie above
+  const bool bad = least < 2u * 0x21800000u - 1u || !(most <= 1152921504606846976.0f) ||
+                   __float_as_uint(d1) - lo > span || __float_as_uint(d2) - lo > span;
+  if (__ballot(bad) == 0) {
+    const float y1 = reciprocal_fast(d1), y2 = reciprocal_fast(d2);
+    const float qx = div_corrected(div_corrected(x.x, d1, y1), d2, y2);
+    const float qy = div_corrected(div_corrected(x.y, d1, y1), d2, y2);
+    const float qz = div_corrected(div_corrected(x.z, d1, y1), d2, y2);
+    return mk(__builtin_copysignf(qx, x.x), __builtin_copysignf(qy, x.y), __builtin_copysignf(qz, x.z));
+  }
+#endif
+  return mk(x.x / d1 / d2, x.y / d1 / d2, x.z / d1 / d2);
+}
+
 // trace_all for two rays that leave the same point, in two phases.
 //
 // 1. One pass over the leaf table (wave-uniform leaf, data in SGPRs, packed arithmetic as
@@ -1318,7 +1343,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   bb.init();
   uint32_t reach_a = 0, reach_b = 0;  // bit j: the ray's line meets sphere j, not behind the origin
   const bool a_half = qa.x >= 0.5f && qa.y >= 0.5f;
-  // n / qa by two fma corrections of n * RN(1/qa) (div_corrected) is the IEEE quotient
+  // n / qa by one fma correction of n * RN(1/qa) (div_corrected) is the IEEE quotient
   // when qa is in [0.5, 2] and |n| is in [2^-40, 2^40]
   const bool a_fast = a_half && qa.x <= 2.0f && qa.y <= 2.0f;
   // RN(1 / qa): qa in [0.5, 2] is well inside reciprocal_fast's range

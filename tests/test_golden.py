@@ -336,7 +336,7 @@ def test_gpu_converged_image_matches_reference(gsc, size):
 
 
 def test_division_free_quotient_is_exact(tmp_path):
-    """The traversal kernels rebuild a/d from RN(1/d) with two fma corrections instead of
+    """The traversal kernels rebuild a/d from RN(1/d) with one fma correction instead of
     dividing (rtr_trace.hpp: div_corrected).  oracle/check_division.c compares that sequence
     with the IEEE quotient over the kernels' operand ranges; any mismatch fails."""
     import subprocess
