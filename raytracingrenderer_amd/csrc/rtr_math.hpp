@@ -49,16 +49,6 @@ RTR_DEV float sqrt_from_rsq(float s, float y) {
   return __builtin_fmaf(d, h, g);
 }
 RTR_DEV float sqrt_ranged(float s) { return sqrt_from_rsq(s, __builtin_amdgcn_rsqf(s)); }
-// 1 / l in double precision to within an ulp, by two Newton steps from an estimate y0 that is good
-// to 2^-22: the estimate's error squares twice (2^-44, 2^-88), what is left is the rounding of the
-// last step.  unit() starts from the hardware's reciprocal square root of the sum of squares, which
-// it needs for the length anyway: that is within 2^-23 of 1 / sqrt(s), and l = RN(sqrt(s)) is within
-// 2^-24 of sqrt(s).
-RTR_DEV double reciprocal_f64_from(double l, double y0) {
-  double y = __builtin_fma(__builtin_fma(-l, y0, 1.0), y0, y0);
-  y = __builtin_fma(__builtin_fma(-l, y, 1.0), y, y);
-  return y;
-}
 RTR_DEV bool tiny_below(float x, uint32_t limit_bits) {  // 0 < |x| < the float with these bits
   return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < limit_bits - 1u;
 }
@@ -68,19 +58,39 @@ RTR_DEV uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
   asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// RN(1/d) without an IEEE division.  hipcc expands 1.0f / d into v_div_scale (twice), v_rcp, six
+// fma steps, v_div_fmas and v_div_fixup.  The hardware's estimate is good to one ulp, and ONE
+// Newton step in fused arithmetic, y1 = y0 + (1 - d y0) y0, already lands on the correctly rounded
+// reciprocal of every float whose magnitude is in [2^-60, 2^60] (reciprocal_operand_fast): not
+// argued but checked -- the self-test entry point compares it with 1.0f / d for every float.
+RTR_DEV bool reciprocal_operand_fast(float d) {
+  const float m = fabsf(d);
+  return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // 2^-60, 2^60
+}
+RTR_DEV float reciprocal_fast(float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+}
+// a / d from y = RN(1/d) by ONE residual correction: q0 = RN(a y), r = a - d q0 (exact in an fma),
+// q = RN(q0 + r y).  Equal to the IEEE quotient whenever no product or residual leaves the normal
+// range -- checked for every pair of significands (tools/ubench/exact_division.hip).  The sign
+// of a zero quotient is lost (-0 comes out as +0).
+RTR_DEV float div_corrected(float a, float d, float y) {
+  const float q = a * y;
+  const float r = __builtin_fmaf(-d, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
 // include/Vector.h:84-87 -- three divisions by the length.
 //
-// An IEEE fp32 division costs about fourteen plain instructions on gfx950 and sqrtf sixteen,
-// and the reference normalises eleven vectors per path vertex.  The quotients a / l of one
-// normalisation share l: with y = 1 / l in double precision (relative error below 2^-51),
-// (float)((double)a * y) is off a / l by less than 2^-50 of its size, and a quotient of two
-// fp32 numbers that is not itself an fp32 number lies at least 2^-49 of its size away from
-// the nearest midpoint between fp32 numbers (its distance from the midpoint, times the
-// denominator's significand, is a non-zero multiple of half an ulp) -- so the rounding to
-// fp32 lands on RN(a / l).  That bound needs a normal quotient: taken when, for every lane of
-// the wave, the sum of squares is in [2^-100, 2^100] and no component is a non-zero number
-// below 2^-60 (zeros are fine and common: wall normals); otherwise the IEEE operations.
-// rtr_self_test runs the quotients on adversarial operands (numerators next to midpoints).
+// An IEEE fp32 division costs as much as seventeen plain instructions on gfx950 and sqrtf
+// twenty-two, and the reference normalises eleven vectors per path vertex.  The quotients a / l
+// of one normalisation share l: RN(1 / l) by reciprocal_fast, each quotient by div_corrected, the
+// numerator's sign put back (zero components are common -- wall normals -- and of either sign).
+// Taken when, for every lane of the wave, the sum of squares is in [2^-100, 2^100] and no
+// component is a non-zero number below 2^-60: then l is in [2^-50, 2^50], every quotient is zero
+// or of magnitude in [2^-110, 1], and no product or residual leaves the normal range; otherwise the
+// IEEE operations.  rtr_self_test runs it on adversarial operands (numerators next to midpoints).
 //
 // The guard is written for the instruction rates of gfx950 (tools/ubench/issue_cycles.hip:
 // additions and subtractions, integer ones included, issue at twice the rate of comparisons,
@@ -98,10 +108,10 @@ RTR_DEV V3 unit(V3 a) {
   // bits(2^-100) = 0x0d800000, bits(2^100) = 0x71800000: negative numbers and NaNs wrap or lie above
   const bool bad = least < 2u * 0x21800000u - 1u || __float_as_uint(s) - 0x0d800000u > 0x71800000u - 0x0d800000u;
   if (__ballot(bad) == 0) {
-    const float y = __builtin_amdgcn_rsqf(s);
-    const float l = sqrt_from_rsq(s, y);
-    const double r = reciprocal_f64_from((double)l, (double)y);
-    return mk((float)((double)a.x * r), (float)((double)a.y * r), (float)((double)a.z * r));
+    const float l = sqrt_ranged(s);
+    const float y = reciprocal_fast(l);
+    return mk(__builtin_copysignf(div_corrected(a.x, l, y), a.x), __builtin_copysignf(div_corrected(a.y, l, y), a.y),
+              __builtin_copysignf(div_corrected(a.z, l, y), a.z));
   }
   const float l = sqrtf(s);
   return mk(a.x / l, a.y / l, a.z / l);

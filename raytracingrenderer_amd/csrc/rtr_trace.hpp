@@ -240,12 +240,7 @@ RTR_DEV HitRec trace_tree(const Geom &g, V3 o, V3 dir, V3 dn, MergeStack &st) {
 // All values are finite, so plain min/max equal the reference's swap-and-select.
 // (A zero quotient may come out as +0 where IEEE gives -0; the two compare equal in
 // every min, max and <= of the test, so its boolean is unaffected.)
-RTR_DEV float div_corrected(float a, float d, float y) {
-  const float q = a * y;
-  const float r = __builtin_fmaf(-d, q, a);
-  return __builtin_fmaf(r, y, q);
-}
-
+// (div_corrected and reciprocal_fast themselves: rtr_math.hpp)
 // Two quotients at a time: gfx950 issues packed fp32 multiply / fma (two IEEE
 // operations per lane and instruction) at the rate of the scalar forms, and the
 // two planes of an axis share d and y.
@@ -257,19 +252,6 @@ RTR_DEV f32x2 div_corrected2(f32x2 a, float d, float y) {
   return __builtin_elementwise_fma(r, yy, q);
 }
 
-// RN(1/d) without an IEEE division.  hipcc expands 1.0f / d into v_div_scale (twice), v_rcp, six
-// fma steps, v_div_fmas and v_div_fixup.  The hardware's estimate is good to one ulp, and ONE
-// Newton step in fused arithmetic, y1 = y0 + (1 - d y0) y0, already lands on the correctly rounded
-// reciprocal of every float whose magnitude is in [2^-60, 2^60] (reciprocal_operand_fast): not
-// argued but checked -- the self-test entry point compares it with 1.0f / d for every float.
-RTR_DEV bool reciprocal_operand_fast(float d) {
-  const float m = fabsf(d);
-  return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // 2^-60, 2^60
-}
-RTR_DEV float reciprocal_fast(float d) {
-  const float y0 = __builtin_amdgcn_rcpf(d);
-  return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
-}
 // 1.0f / d, by the short sequence when every lane of the wave may take it
 RTR_DEV f32x2 reciprocal_pair(f32x2 d) {
   const bool slow = !(reciprocal_operand_fast(d.x) && reciprocal_operand_fast(d.y));
