@@ -206,6 +206,28 @@ int rtr_device_count(int *n);
  */
 int rtr_self_test(int device, uint64_t *mismatches);
 
+/*
+ * BVH::selfBuildBVH (src/BVH.cpp:19-64) on the device: the tree over n_objects boxes that the
+ * reference builds -- at every node the box of all objects (Bound3::merge, include/Bound3.h:14-20),
+ * the objects sorted by box centre (Bound3::getCenterPos) along the box's longest axis with
+ * std::sort, the first half (rounded down) to the left child -- with the same objects in the
+ * same leaves, INCLUDING where several objects have equal sort keys: there the split depends on
+ * the order in which libstdc++'s introsort leaves equal keys, and the kernels reproduce that
+ * order (median-of-three Hoare partitions by parallel ranks, heap sort where the depth budget
+ * runs out, the final insertion sort as a stable ranking).  Box planes carry the reference's bits,
+ * the sign of a zero plane included.
+ * obj_bmin / obj_bmax: the objects' boxes (Object::getBound), [0]=x [1]=y [2]=z, host memory; all
+ * planes must be finite.  Outputs (host memory, 2 * n_objects - 1 nodes, node 0 is the root,
+ * numbered level by level): the nodes' boxes, children (-1 for a leaf) and the leaf's object
+ * index (-1 for an inner node) -- the node arrays of rtr_scene_desc once object indices are
+ * replaced by prim ids.  root_order (may be NULL): the n_objects object indices in the order the
+ * root's sort leaves them, which is how the reference leaves the caller's vector (it sorts
+ * `objs` in place at the root and copies of its halves below).
+ */
+int rtr_build_bvh(int device, int32_t n_objects, const float *const obj_bmin[3],
+                  const float *const obj_bmax[3], float *const node_bmin[3], float *const node_bmax[3],
+                  int32_t *node_left, int32_t *node_right, int32_t *node_object, int32_t *root_order);
+
 /* Uploads the scene to `device` (copies everything; the desc may be freed).  The tree is
  * checked, renumbered in depth-first order and laid out in records by kernels on the device
  * (BVH::selfBuildBVH's result, src/BVH.cpp:19-64, is taken as given: its topology and

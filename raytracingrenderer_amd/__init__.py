@@ -14,5 +14,5 @@ libraries are missing, importing :mod:`raytracingrenderer_amd.api` raises.
 """
 from .api import (  # noqa: F401
     DIFFUSE, MICROFACET, MODE_AUTO, MODE_FUSED, MODE_WAVEFRONT, SPECULAR, HostScene, RenderParams, RtrError, Stats, default_scene,
-    device_count, hip_lib, host_lib, partition_columns, save_ppm, self_test,
+    build_bvh, device_count, hip_lib, host_lib, partition_columns, save_ppm, self_test,
 )

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "rtr_partition_columns", "rtr_check_connectable", "rtr_create_photon_map",
     "rtr_create_photon_map_device", "rtr_render_pt_device_noalloc", "rtr_render_pt_multi",
     "rtr_render_pt_multi_device", "rtr_trace_count_work", "rtr_self_test", "rtr_scene_read_tree",
-    "rtr_scene_read_pairs",
+    "rtr_scene_read_pairs", "rtr_build_bvh",
 ]
 
 _hip = None
@@ -112,6 +112,8 @@ def hip_lib():
                                                  C.POINTER(RenderParams), C.c_void_p,
                                                  C.POINTER(Stats)]
         L.rtr_partition_columns.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip]
+        L.rtr_build_bvh.argtypes = [C.c_int, C.c_int32, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),
+                                    C.POINTER(_fp), _ip, _ip, _ip, _ip]
         _hip = L
     return _hip
 
@@ -199,6 +201,26 @@ def self_test(device=0):
     L.rtr_self_test.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     _check(L.rtr_self_test(device, C.byref(n)), "rtr_self_test")
     return n.value
+
+
+def build_bvh(bmin, bmax, device=0):
+    """rtr_build_bvh: the reference's BVH::selfBuildBVH over boxes bmin / bmax (n x 3), built on
+    the device.  Returns (node_bmin[N,3], node_bmax[N,3], left[N], right[N], object[N],
+    root_order[n]) with N = 2n - 1, node 0 the root."""
+    bmin = np.ascontiguousarray(np.asarray(bmin, f32).reshape(-1, 3).T)
+    bmax = np.ascontiguousarray(np.asarray(bmax, f32).reshape(-1, 3).T)
+    n = bmin.shape[1]
+    N = max(2 * n - 1, 1)
+    nlo = np.zeros((3, N), f32)
+    nhi = np.zeros((3, N), f32)
+    left = np.zeros(N, np.int32)
+    right = np.zeros(N, np.int32)
+    obj = np.zeros(N, np.int32)
+    order = np.zeros(max(n, 1), np.int32)
+    axes = lambda a: (_fp * 3)(*[_f(a[k]) for k in range(3)])
+    _check(hip_lib().rtr_build_bvh(device, n, axes(bmin), axes(bmax), axes(nlo), axes(nhi), _i(left),
+                                   _i(right), _i(obj), _i(order)), "rtr_build_bvh")
+    return nlo.T.copy(), nhi.T.copy(), left, right, obj, order
 
 
 def partition_columns(width, part_index, part_count, tile_cols=8):

@@ -26,6 +26,15 @@ int fail(int code, const std::string &msg) {
   return code;
 }
 
+}  // namespace
+
+namespace rtr {
+// for the library's other translation units: sets what rtr_last_error() returns
+int fail_msg(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace rtr
+
+namespace {
+
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \

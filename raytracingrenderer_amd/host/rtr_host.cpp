@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <iostream>
@@ -165,10 +166,69 @@ BVHNode *BVH::build(std::vector<Object *> &objs) {
   return tb.build(0, objs.size(), (int)hw - 1, &objs);
 }
 
-void BVH::buildBVH(std::vector<Object *> &objs) {
-  destroy(root);
+BVH::Builder BVH::builder = BVH::Auto;
+size_t BVH::deviceMin = 1 << 13;
+int BVH::buildDevice = 0;
+
+void BVH::clear() {
+  if (arena.empty()) destroy(root);
+  arena.clear();
+  arena.shrink_to_fit();
   root = nullptr;
-  root = build(objs);
+}
+
+// BVH::selfBuildBVH by the kernels behind rtr_build_bvh: the objects' boxes go over, node arrays
+// come back (numbered level by level, node 0 the root) and become BVHNodes in one block.
+BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
+  const size_t n = objs.size(), nn = 2 * n - 1;
+  std::vector<float> ob[6], nb[6];
+  for (int a = 0; a < 6; a++) ob[a].resize(n), nb[a].resize(nn);
+  for (size_t k = 0; k < n; k++) {
+    const Bound3 b = objs[k]->getBound();
+    ob[0][k] = b.min.x, ob[1][k] = b.min.y, ob[2][k] = b.min.z;
+    ob[3][k] = b.max.x, ob[4][k] = b.max.y, ob[5][k] = b.max.z;
+  }
+  std::vector<int32_t> left(nn), right(nn), object(nn), order(n);
+  const float *omin[3] = {ob[0].data(), ob[1].data(), ob[2].data()};
+  const float *omax[3] = {ob[3].data(), ob[4].data(), ob[5].data()};
+  float *nmin[3] = {nb[0].data(), nb[1].data(), nb[2].data()};
+  float *nmax[3] = {nb[3].data(), nb[4].data(), nb[5].data()};
+  if (rtr_build_bvh(buildDevice, (int32_t)n, omin, omax, nmin, nmax, left.data(), right.data(),
+                    object.data(), order.data()) != RTR_OK)
+    throw std::runtime_error(std::string("rtr_build_bvh: ") + rtr_last_error());
+  arena.resize(nn);
+  for (size_t i = 0; i < nn; i++) {
+    BVHNode &node = arena[i];
+    node.bound = Bound3(Vector3f(nb[0][i], nb[1][i], nb[2][i]), Vector3f(nb[3][i], nb[4][i], nb[5][i]));
+    node.left = left[i] >= 0 ? &arena[left[i]] : nullptr;
+    node.right = right[i] >= 0 ? &arena[right[i]] : nullptr;
+    node.object = object[i] >= 0 ? objs[object[i]] : nullptr;
+  }
+  std::vector<Object *> sorted(n);
+  for (size_t k = 0; k < n; k++) sorted[k] = objs[order[k]];
+  objs.swap(sorted);
+  return &arena[0];
+}
+
+void BVH::buildBVH(std::vector<Object *> &objs) {
+  clear();
+  Builder how = builder;
+  if (const char *env = getenv("RTR_TREE_BUILDER")) {
+    if (!strcmp(env, "host")) how = Host;
+    else if (!strcmp(env, "device")) how = Device;
+  }
+  bool on_device = how == Device && !objs.empty();
+  if (how == Auto && objs.size() >= deviceMin) {
+    int devices = 0;
+    on_device = rtr_device_count(&devices) == RTR_OK && devices > buildDevice;
+    if (on_device)  // the kernels take finite boxes only; anything else is the host's
+      for (Object *o : objs) {
+        const Bound3 b = o->getBound();
+        const float v[6] = {b.min.x, b.min.y, b.min.z, b.max.x, b.max.y, b.max.z};
+        for (float f : v) on_device = on_device && std::isfinite(f);
+      }
+  }
+  root = on_device ? buildOnDevice(objs) : build(objs);
 }
 
 // ---------------- TrangleMesh (include/Trangle.h:60-95) ----------------

@@ -129,12 +129,22 @@ struct BVHNode {
 
 class BVH {
   BVHNode *root = nullptr;
+  std::vector<BVHNode> arena;  // the nodes of a tree that came from the device as arrays
   static BVHNode *build(std::vector<Object *> &objs);
+  BVHNode *buildOnDevice(std::vector<Object *> &objs);
   static void destroy(BVHNode *n);
+  void clear();
 
  public:
+  // Where trees are built.  Auto: on the device (rtr_build_bvh) from deviceMin objects on when a
+  // GPU is present, else by std::sort on the host; both give the reference's tree bit for bit.
+  // The environment variable RTR_TREE_BUILDER = host | device overrides the setting.
+  enum Builder { Auto, Host, Device };
+  static Builder builder;
+  static size_t deviceMin;
+  static int buildDevice;
   BVH() {}
-  ~BVH() { destroy(root); }
+  ~BVH() { clear(); }
   BVH(const BVH &) = delete;
   BVH &operator=(const BVH &) = delete;
   // sorts objs in place like the reference does (src/BVH.cpp:42-55)

@@ -1,0 +1,151 @@
+"""The tree builder on the device (rtr_build_bvh; reference BVH::selfBuildBVH, src/BVH.cpp:19-64)
+against the host mirror's builder, which sorts with std::sort like the reference and is pinned to
+the reference on the CPU (tests/test_oracle_vs_ref.py::test_grid_mesh_with_tied_sort_keys,
+tests/test_host_cpu.py).  Every array of the flattened tree must agree bit for bit -- boxes, children,
+leaf objects -- which for meshes whose sort keys tie means the kernels left equal keys in the very
+order libstdc++'s introsort leaves them."""
+import os
+
+import numpy as np
+import pytest
+
+import _rays
+from raytracingrenderer_amd.scenes import default_scene_spec, heightfield_spec
+
+f32 = np.float32
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracingrenderer_amd as rt
+    if rt.device_count() < 1:
+        pytest.fail("no HIP device: the GPU tests need one (there is no CPU fallback)")
+    return rt
+
+
+def _mesh_only(verts, idx):
+    spec = default_scene_spec()
+    spec["objects"] = [("mesh", "white", np.asarray(verts, f32), np.asarray(idx, np.uint32))]
+    return spec
+
+
+def _flatten_with(rt, spec, builder):
+    os.environ["RTR_TREE_BUILDER"] = builder
+    try:
+        s = rt.HostScene.from_spec(spec)
+        out = s.flatten()
+        s.close()
+    finally:
+        del os.environ["RTR_TREE_BUILDER"]
+    return out
+
+
+def _assert_same_tree(rt, spec):
+    host = _flatten_with(rt, spec, "host")
+    dev = _flatten_with(rt, spec, "device")
+    for name, a, b in zip(("bmin", "bmax", "children", "prim"), host, dev):
+        same = _rays.bits(a) == _rays.bits(b)
+        assert same.all(), "%s differs at %d of %d nodes, first at node %d" % (
+            name, (~same.reshape(len(a), -1).all(1)).sum(), len(a),
+            np.argmin(same.reshape(len(a), -1).all(1)))
+
+
+def _soup(n, rng, extent=512.0):
+    """n small random triangles."""
+    c = rng.uniform(0, extent, (n, 1, 3))
+    v = (c + rng.uniform(-2, 2, (n, 3, 3))) * np.array([1, 1, -1])
+    return v.reshape(-1, 3).astype(f32), np.arange(3 * n, dtype=np.uint32)
+
+
+def _points_on_a_line(keys):
+    """One degenerate triangle (a point) per key: box centre = (key, 0, 0), so the tree is the
+    sort of `keys` and nothing else."""
+    keys = np.asarray(keys, f32)
+    v = np.zeros((len(keys), 3, 3), f32)
+    v[:, :, 0] = keys[:, None]
+    return v.reshape(-1, 3), np.arange(3 * len(keys), dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 31, 33, 100, 1000, 2047, 2048, 2049, 4097, 10000, 70001])
+def test_random_triangles(rt, n):
+    v, i = _soup(n, np.random.default_rng(n))
+    _assert_same_tree(rt, _mesh_only(v, i))
+
+
+@pytest.mark.parametrize("cells", [3, 30, 150, 400])
+def test_grid_meshes_with_tied_keys(rt, cells):
+    """Height fields over a regular grid: whole rows of triangles share a box centre on two axes."""
+    spec = heightfield_spec(cells)
+    spec["objects"] = spec["objects"][-1:]
+    _assert_same_tree(rt, spec)
+
+
+@pytest.mark.parametrize("n,kind", [(40, "equal"), (5000, "equal"), (100000, "equal"),
+                                    (3000, "sorted_runs"), (200000, "sorted_runs"),
+                                    (3000, "reversed_runs"), (150000, "reversed_runs"),
+                                    (50000, "few_values"), (50000, "strided"), (120000, "organ_pipe"),
+                                    (60000, "signed_zeros")])
+def test_sorts_that_depend_on_tie_order(rt, n, kind):
+    """Key sequences that drive std::sort through its corners: all keys equal, sorted and reversed
+    input in runs of equal keys (these exhaust the depth budget and end in heap sorts), few distinct
+    values, zeros of both signs."""
+    rng = np.random.default_rng(n)
+    i = np.arange(n)
+    keys = {"equal": np.full(n, 7.0),
+            "sorted_runs": i // 5,
+            "reversed_runs": (n - i) // 3,
+            "few_values": rng.integers(0, 11, n),
+            "strided": (i * 7919) % 1013,
+            "organ_pipe": np.minimum(i, n - i) // 2,
+            "signed_zeros": np.where(rng.random(n) < 0.5, 0.0, -0.0) * 1.0 + (rng.random(n) < 0.1) * rng.integers(-3, 4, n)}[kind]
+    v, idx = _points_on_a_line(keys)
+    _assert_same_tree(rt, _mesh_only(v, idx))
+
+
+def test_million_triangle_tree(rt):
+    """The 1 M-triangle height field of the large-scene measurements."""
+    spec = heightfield_spec(708)
+    spec["objects"] = spec["objects"][-1:]
+    _assert_same_tree(rt, spec)
+
+
+def test_root_order_and_raw_arrays(rt):
+    """rtr_build_bvh itself: node 0 is the root, 2n - 1 nodes, every object in one leaf, and
+    root_order is the root's sort."""
+    rng = np.random.default_rng(3)
+    n = 5000
+    lo = rng.uniform(0, 100, (n, 3)).astype(f32)
+    hi = lo + rng.uniform(0, 3, (n, 3)).astype(f32)
+    nlo, nhi, left, right, obj, order = rt.build_bvh(lo, hi)
+    assert len(left) == 2 * n - 1
+    leaves = left < 0
+    assert leaves.sum() == n and (right[leaves] < 0).all() and (obj[~leaves] < 0).all()
+    assert sorted(obj[leaves]) == list(range(n)) and sorted(order) == list(range(n))
+    assert np.array_equal(nlo[0], lo.min(0)) and np.array_equal(nhi[0], hi.max(0))
+    ext = nhi[0] - nlo[0]
+    axis = 0 if ext[0] > ext[1] and ext[0] > ext[2] else (1 if ext[1] > ext[2] else 2)
+    key = lo[:, axis] * f32(0.5) + hi[:, axis] * f32(0.5)
+    assert (np.diff(key[order]) >= 0).all()
+    # the left half of the root's order is the set of objects under the root's left child
+    def under(node):
+        stack, out = [node], []
+        while stack:
+            k = stack.pop()
+            if left[k] < 0:
+                out.append(obj[k])
+            else:
+                stack += [left[k], right[k]]
+        return sorted(out)
+    assert under(left[0]) == sorted(order[:n // 2])
+
+
+def test_infinite_boxes_are_refused(rt):
+    lo = np.zeros((10, 3), f32)
+    hi = np.ones((10, 3), f32)
+    hi[4, 1] = np.inf
+    with pytest.raises(rt.RtrError):
+        rt.build_bvh(lo, hi)
+    lo[2, 0] = np.nan
+    with pytest.raises(rt.RtrError):
+        rt.build_bvh(lo, np.ones((10, 3), f32))
