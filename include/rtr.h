@@ -217,8 +217,9 @@ int rtr_self_test(int device, uint64_t *mismatches);
  * runs out, the final insertion sort as a stable ranking).  Box planes carry the reference's bits,
  * the sign of a zero plane included.
  * obj_bmin / obj_bmax: the objects' boxes (Object::getBound), [0]=x [1]=y [2]=z, host memory; all
- * planes must be finite.  Outputs (host memory, 2 * n_objects - 1 nodes, node 0 is the root,
- * numbered level by level): the nodes' boxes, children (-1 for a leaf) and the leaf's object
+ * planes must be finite.  Outputs (host memory, 2 * n_objects - 1 nodes, numbered depth first,
+ * left child first -- node 0 is the root, the left child of node i is node i + 1, which is the
+ * order BVH::intersect, src/BVH.cpp:66-80, visits them in): the nodes' boxes, children (-1 for a leaf) and the leaf's object
  * index (-1 for an inner node) -- the node arrays of rtr_scene_desc once object indices are
  * replaced by prim ids.  root_order (may be NULL): the n_objects object indices in the order the
  * root's sort leaves them, which is how the reference leaves the caller's vector (it sorts

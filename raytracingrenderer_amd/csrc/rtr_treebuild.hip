@@ -38,10 +38,12 @@
 // builds the whole subtree below it in LDS.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
-#include <vector>
 
 #include "../../include/rtr.h"
 #include "rtr_heapsort.hpp"
@@ -72,44 +74,37 @@ struct NodeOut {
 };
 
 // ---- ranges of the tree: floor half to the left, the rest to the right (src/BVH.cpp:58-59) ----
-__device__ inline void range_of_position(int n, int L, int p, int &k, int &lo, int &s) {
-  lo = 0, s = n, k = 0;
+// Nodes are numbered depth first, left child first (the order BVH::intersect visits them): a
+// subtree over s objects has 2s - 1 nodes, so the left child of node i is i + 1 and the right child
+// i + 2 * floor(s / 2); every walk down the ranges carries the node number along.
+__device__ inline void range_of_position(int n, int L, int p, int &k, int &lo, int &s, int &id) {
+  lo = 0, s = n, k = 0, id = 0;
   for (int b = 0; b < L; b++) {
     const int h = s >> 1;
-    if (p >= lo + h) lo += h, s -= h, k = 2 * k + 1;
-    else s = h, k = 2 * k;
+    if (p >= lo + h) lo += h, s -= h, k = 2 * k + 1, id += 2 * h;
+    else s = h, k = 2 * k, id += 1;
   }
 }
-__host__ __device__ inline void range_of_index(int n, int L, int k, int &lo, int &s) {
-  lo = 0, s = n;
+__host__ __device__ inline void range_of_index(int n, int L, int k, int &lo, int &s, int &id) {
+  lo = 0, s = n, id = 0;
   for (int b = L - 1; b >= 0; b--) {
     const int h = s >> 1;
-    if ((k >> b) & 1) lo += h, s -= h;
-    else s = h;
+    if ((k >> b) & 1) lo += h, s -= h, id += 2 * h;
+    else s = h, id += 1;
   }
 }
-// like range_of_position, inside one range of m objects; alive = the walk did not pass a range of
-// one object before depth j (such a position became a leaf further up)
-__device__ inline bool subrange_of_position(int m, int j, int p, int &k, int &lo, int &s) {
-  lo = 0, s = m, k = 0;
+// like range_of_position, inside one range of m objects (id counts from that range's node);
+// alive = the walk did not pass a range of one object before depth j (such a position became a
+// leaf further up)
+__device__ inline bool subrange_of_position(int m, int j, int p, int &k, int &lo, int &s, int &id) {
+  lo = 0, s = m, k = 0, id = 0;
   for (int b = 0; b < j; b++) {
     if (s == 1) return false;
     const int h = s >> 1;
-    if (p >= lo + h) lo += h, s -= h, k = 2 * k + 1;
-    else s = h, k = 2 * k;
+    if (p >= lo + h) lo += h, s -= h, k = 2 * k + 1, id += 2 * h;
+    else s = h, k = 2 * k, id += 1;
   }
   return true;
-}
-
-// Node numbers: level by level.  Levels 0 .. Lc = floor(log2 n) are complete (2^L nodes); ranges
-// of level Lc hold one or two objects, and the children of those with two follow, in order.
-__device__ inline int node_number(int L, int Lc, int k, int lo) {
-  if (L <= Lc) return (1 << L) - 1 + k;
-  const int lo_parent = lo - (k & 1), k_parent = k >> 1;
-  return (2 << Lc) - 1 + 2 * (lo_parent - k_parent) + (k & 1);
-}
-__device__ inline int left_child_number(int L, int Lc, int k, int lo) {
-  return L < Lc ? (2 << L) - 1 + 2 * k : (2 << Lc) - 1 + 2 * (lo - k);
 }
 
 __device__ inline int floor_log2(int v) { return 31 - __clz(v); }
@@ -164,76 +159,63 @@ __global__ void __launch_bounds__(256) k_tb_fill64(unsigned long long *a, int co
   if (i < count_all) a[i] = i < count_min ? kMinIdentity : kMaxIdentity;
 }
 
-// boxes of all ranges of level L: planes[a << L | k], a = 0..2 minima, 3..5 maxima
-__global__ void __launch_bounds__(256)
+// boxes of all ranges of level L: planes[a << L | k], a = 0..2 minima, 3..5 maxima.  A wave whose
+// positions are all in one range reduces before it touches memory, and so does a workgroup whose
+// waves are: the upper levels would otherwise queue a hundred thousand atomics on six words.
+constexpr int kBoxWG = 1024;
+__global__ void __launch_bounds__(kBoxWG)
 k_tb_level_boxes(int n, int L, const uint32_t *idx, const float *box, unsigned long long *planes) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  __shared__ unsigned long long wave_planes[kBoxWG / 64][6];
+  __shared__ int wave_range[kBoxWG / 64];  // the wave's range, -1: none (all beyond n), -2: several
+  const int p = blockIdx.x * kBoxWG + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool live = p < n;
-  int k = -1, lo, s;
+  int k = -1, lo, s, id;
   unsigned long long v[6];
+  for (int a = 0; a < 3; a++) v[a] = kMinIdentity, v[3 + a] = kMaxIdentity;
   if (live) {
-    range_of_position(n, L, p, k, lo, s);
+    range_of_position(n, L, p, k, lo, s, id);
     const uint32_t o = idx[p];
     for (int a = 0; a < 3; a++) {
       v[a] = pack_min(box[(size_t)a * n + o], (uint32_t)p);
       v[3 + a] = pack_max(box[(size_t)(3 + a) * n + o], (uint32_t)p);
     }
-  } else {
-    for (int a = 0; a < 3; a++) v[a] = kMinIdentity, v[3 + a] = kMaxIdentity;
   }
-  const int k0 = __shfl(k, 0);
-  if (k0 < 0) return;  // lane 0 of a wave holds its lowest position
-  if (__all(!live || k == k0)) {
+  const int k0 = __shfl(k, 0);  // lane 0 of a wave holds its lowest position
+  const bool uniform = k0 >= 0 && __all(!live || k == k0);
+  if (uniform) {
     for (int off = 32; off > 0; off >>= 1)
       for (int a = 0; a < 3; a++) {
         const unsigned long long m = __shfl_xor(v[a], off), x = __shfl_xor(v[3 + a], off);
         v[a] = m < v[a] ? m : v[a];
         v[3 + a] = x > v[3 + a] ? x : v[3 + a];
       }
-    if ((threadIdx.x & 63) == 0)
-      for (int a = 0; a < 3; a++) {
-        atomicMin(&planes[((size_t)a << L) + k0], v[a]);
-        atomicMax(&planes[((size_t)(3 + a) << L) + k0], v[3 + a]);
-      }
+    if (lane == 0)
+      for (int a = 0; a < 6; a++) wave_planes[wave][a] = v[a];
   } else if (live) {
     for (int a = 0; a < 3; a++) {
       atomicMin(&planes[((size_t)a << L) + k], v[a]);
       atomicMax(&planes[((size_t)(3 + a) << L) + k], v[3 + a]);
     }
   }
-}
-
-__device__ inline void push_range(QsRange *list, int *count, int f, int l, int depth) {
-  const int at = atomicAdd(count, 1);
-  list[at] = QsRange{f, l, depth, 0};
-}
-
-// node records of level L, sort keys of its objects, and the ranges to sort
-__global__ void __launch_bounds__(256)
-k_tb_level_keys(int n, int L, int Lc, const uint32_t *idx, const float *box,
-                const unsigned long long *planes, float *key, NodeOut out, QsRange *big, int *n_big,
-                QsRange *small, int *n_small) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  int k, lo, s;
-  range_of_position(n, L, p, k, lo, s);
-  float bl[3], bh[3];
-  for (int a = 0; a < 3; a++) {
-    bl[a] = unpack_plane(planes[((size_t)a << L) + k]);
-    bh[a] = unpack_plane(planes[((size_t)(3 + a) << L) + k]);
+  if (lane == 0) wave_range[wave] = uniform ? k0 : (k0 < 0 ? -1 : -2);
+  __syncthreads();
+  // plane a of the workgroup's first range by lane a of wave 0; other waves' ranges by themselves
+  const int kw = wave_range[0];
+  if (wave == 0 && lane < 6 && kw >= 0) {
+    unsigned long long r = wave_planes[0][lane];
+    for (int w = 1; w < kBoxWG / 64; w++)
+      if (wave_range[w] == kw) {
+        const unsigned long long o = wave_planes[w][lane];
+        r = lane < 3 ? (o < r ? o : r) : (o > r ? o : r);
+      }
+    if (lane < 3) atomicMin(&planes[((size_t)lane << L) + kw], r);
+    else atomicMax(&planes[((size_t)lane << L) + kw], r);
   }
-  const int axis = longest_axis(bl, bh);
-  const uint32_t o = idx[p];
-  key[p] = centre_key(box[(size_t)axis * n + o], box[(size_t)(3 + axis) * n + o]);
-  if (p != lo) return;
-  const int id = node_number(L, Lc, k, lo);
-  for (int a = 0; a < 3; a++) out.bmin[a][id] = bl[a], out.bmax[a][id] = bh[a];
-  const int lc = left_child_number(L, Lc, k, lo);  // ranges of these levels hold at least two objects
-  out.left[id] = lc;
-  out.right[id] = lc + 1;
-  out.object[id] = -1;
-  if (s > kT) push_range(big, n_big, lo, lo + s, 2 * floor_log2(s));
-  else push_range(small, n_small, lo, lo + s, 2 * floor_log2(s));
+  if (wave > 0 && lane < 6 && wave_range[wave] >= 0 && wave_range[wave] != kw) {
+    const unsigned long long r = wave_planes[wave][lane];
+    if (lane < 3) atomicMin(&planes[((size_t)lane << L) + wave_range[wave]], r);
+    else atomicMax(&planes[((size_t)lane << L) + wave_range[wave]], r);
+  }
 }
 
 struct GlobalRecords {
@@ -243,66 +225,190 @@ struct GlobalRecords {
   __device__ void set(int i, rtr::SortRec r) const { key[i] = r.key, idx[i] = r.id; }
 };
 
-// One round of the introsort recursion for one range of more than kT objects: median of three to
-// the front, Hoare partition by ranks, the two parts queued.  Two passes over the range: ranks
-// (positions of the swap candidates written to PL / PR), then the swaps.
+// A range of more than kT objects on its way through one round of the introsort recursion.  Its
+// partition is cut into tiles of kTile positions, one workgroup each; tile numbers run through
+// all ranges of the round (tile_base = tiles of the ranges queued before it).
+constexpr int kTile = kBigWG * kBigE;
+struct BigRange {
+  int f, l, depth, tile_base;
+  int K, cl, cr, pad;  // swaps made, candidates on either side (set by the swap pass)
+};
+struct SortQueues {
+  BigRange *big[2];                 // this round's and the next round's large ranges
+  unsigned long long *big_count;    // [2]: ranges << 32 | tiles
+  QsRange *small;                   // ranges of at most kT objects, finished in LDS
+  int *small_count;
+  uint32_t *tile_counts;            // per tile: left | right << 16 candidates
+};
+
+__device__ inline void push_small(const SortQueues &q, int f, int l, int depth) {
+  q.small[atomicAdd(q.small_count, 1)] = QsRange{f, l, depth, 0};
+}
+// Queues [f, l) for the next round: the median of three goes to the front now (the range is at
+// rest between rounds), so that every tile of the round finds the pivot at f.  A range whose depth
+// budget is spent is heap-sorted here, by this one lane, and not queued.
+__device__ inline void push_big(const SortQueues &q, int to, GlobalRecords rec, int f, int l, int depth) {
+  if (depth == 0) return rtr::heap_sort(rec, f, l);
+  rtr::median_to_first(rec, f, f + 1, f + (l - f) / 2, l - 1);
+  const int tiles = (l - f - 1 + kTile - 1) / kTile;
+  const unsigned long long old = atomicAdd(&q.big_count[to], (1ull << 32) | (unsigned long long)tiles);
+  q.big[to][(int)(old >> 32)] = BigRange{f, l, depth, (int)(old & 0xffffffffu), 0, 0, 0, 0};
+}
+
+// node records of level L and the sort keys of its objects
+__global__ void __launch_bounds__(256)
+k_tb_level_keys(int n, int L, const uint32_t *idx, const float *box,
+                const unsigned long long *planes, float *key, NodeOut out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  int k, lo, s, id;
+  range_of_position(n, L, p, k, lo, s, id);
+  float bl[3], bh[3];
+  for (int a = 0; a < 3; a++) {
+    bl[a] = unpack_plane(planes[((size_t)a << L) + k]);
+    bh[a] = unpack_plane(planes[((size_t)(3 + a) << L) + k]);
+  }
+  const int axis = longest_axis(bl, bh);
+  const uint32_t o = idx[p];
+  key[p] = centre_key(box[(size_t)axis * n + o], box[(size_t)(3 + axis) * n + o]);
+  if (p != lo) return;
+  for (int a = 0; a < 3; a++) out.bmin[a][id] = bl[a], out.bmax[a][id] = bh[a];
+  out.left[id] = id + 1;  // ranges of these levels hold at least two objects
+  out.right[id] = id + 2 * (s >> 1);
+  out.object[id] = -1;
+}
+
+// the ranges of level L, queued for their sort (after every key of the level is written)
+__global__ void __launch_bounds__(256)
+k_tb_level_ranges(int n, int L, SortQueues q, uint32_t *idx, float *key) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= (1 << L)) return;
+  int lo, s, id;
+  range_of_index(n, L, k, lo, s, id);
+  if (s > kT) push_big(q, 0, GlobalRecords{key, idx}, lo, lo + s, 2 * floor_log2(s));
+  else push_small(q, lo, lo + s, 2 * floor_log2(s));
+}
+
+// which range a tile belongs to: the last one whose tile_base is not beyond it
+__device__ inline int range_of_tile(const BigRange *list, int count, int tile) {
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (list[mid].tile_base <= tile) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+// One round of the introsort recursion over all large ranges, three passes of one workgroup per
+// tile: candidates counted (k_tb_count), their positions written in rank order to PL / PR
+// (k_tb_scatter), the swaps (k_tb_swap); then one lane per range queues the two parts (k_tb_finish).
+struct TileFlags {
+  uint32_t left, right;  // bit e: position e * kBigWG + lane of the tile is a candidate
+};
+__device__ inline TileFlags tile_flags(const BigRange &rg, int t, const float *key) {
+  const float pivot = key[rg.f];
+  TileFlags fl{0u, 0u};
+  for (int e = 0; e < kBigE; e++) {
+    const int p = rg.f + 1 + t * kTile + e * kBigWG + (int)threadIdx.x;
+    if (p < rg.l) {
+      const float kv = key[p];
+      fl.left |= (!(kv < pivot) ? 1u : 0u) << e;
+      fl.right |= (!(pivot < kv) ? 1u : 0u) << e;
+    }
+  }
+  return fl;
+}
+
 __global__ void __launch_bounds__(kBigWG)
-k_tb_partition(const QsRange *in, uint32_t *idx, float *key, uint32_t *PL, uint32_t *PR, QsRange *big,
-               int *n_big, QsRange *small, int *n_small) {
-  __shared__ uint32_t wave_total[2][kBigE * (kBigWG / 64)];
-  __shared__ int sK;
-  const QsRange rg = in[blockIdx.x];
-  const int f = rg.f, l = rg.l, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  GlobalRecords rec{key, idx};
-  if (rg.depth == 0) {
-    if (tid == 0) rtr::heap_sort(rec, f, l);
-    return;
+k_tb_count(const BigRange *list, int count, const float *key, uint32_t *tile_counts) {
+  __shared__ int s_range;
+  __shared__ uint32_t s_sum[2];
+  if (threadIdx.x == 0) s_range = range_of_tile(list, count, blockIdx.x), s_sum[0] = s_sum[1] = 0;
+  __syncthreads();
+  const BigRange rg = list[s_range];
+  const TileFlags fl = tile_flags(rg, blockIdx.x - rg.tile_base, key);
+  uint32_t cl = __popc(fl.left), cr = __popc(fl.right);
+  for (int off = 32; off > 0; off >>= 1) cl += __shfl_xor(cl, off), cr += __shfl_xor(cr, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[0], cl), atomicAdd(&s_sum[1], cr);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_sum[0] | (s_sum[1] << 16);
+}
+
+// sum of the candidates of tiles [from, to), by the whole workgroup: {left, right}
+__device__ inline void sum_tiles(const uint32_t *tile_counts, int from, int to, uint32_t *s_sum,
+                                 uint32_t &left, uint32_t &right) {
+  uint32_t cl = 0, cr = 0;
+  for (int t = from + (int)threadIdx.x; t < to; t += kBigWG) {
+    const uint32_t c = tile_counts[t];
+    cl += c & 0xffffu, cr += c >> 16;
   }
-  if (tid == 0) {
-    rtr::median_to_first(rec, f, f + 1, f + (l - f) / 2, l - 1);
-    sK = 0;
+  for (int off = 32; off > 0; off >>= 1) cl += __shfl_xor(cl, off), cr += __shfl_xor(cr, off);
+  if (threadIdx.x == 0) s_sum[0] = s_sum[1] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[0], cl), atomicAdd(&s_sum[1], cr);
+  __syncthreads();
+  left = s_sum[0], right = s_sum[1];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kBigWG)
+k_tb_scatter(const BigRange *list, int count, const float *key, const uint32_t *tile_counts,
+             uint32_t *PL, uint32_t *PR) {
+  __shared__ int s_range;
+  __shared__ uint32_t s_sum[2];
+  __shared__ uint32_t wave_total[kBigE * (kBigWG / 64)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_range = range_of_tile(list, count, blockIdx.x);
+  __syncthreads();
+  const BigRange rg = list[s_range];
+  const int t = blockIdx.x - rg.tile_base, first = rg.f + 1;
+  uint32_t base_l, base_r;  // candidates in the range's earlier tiles
+  sum_tiles(tile_counts, rg.tile_base, blockIdx.x, s_sum, base_l, base_r);
+  const TileFlags fl = tile_flags(rg, t, key);
+  uint32_t rank[kBigE];  // candidates before this lane in its wave: left | right << 16
+  const unsigned long long below = (1ull << lane) - 1;
+  for (int e = 0; e < kBigE; e++) {
+    const unsigned long long ml = __ballot((fl.left >> e) & 1), mr = __ballot((fl.right >> e) & 1);
+    rank[e] = (uint32_t)__popcll(ml & below) | ((uint32_t)__popcll(mr & below) << 16);
+    if (lane == 0) wave_total[e * (kBigWG / 64) + wave] = (uint32_t)__popcll(ml) | ((uint32_t)__popcll(mr) << 16);
   }
   __syncthreads();
-  const float pivot = key[f];
-  const int first = f + 1, count = l - first;
-  int base_l = 0, base_r = 0;  // candidates seen in earlier trips
-  for (int c0 = 0, trip = 0; c0 < count; c0 += kBigWG * kBigE, trip++) {
-    bool fl[kBigE], fr[kBigE];
-    uint32_t rank[kBigE];  // candidates before this lane in its wave: left | right << 16
-    for (int e = 0; e < kBigE; e++) {
-      const int p = first + c0 + e * kBigWG + tid;
-      const bool in_range = p < l;
-      const float kv = in_range ? key[p] : 0.f;
-      fl[e] = in_range && !(kv < pivot);
-      fr[e] = in_range && !(pivot < kv);
-      const unsigned long long ml = __ballot(fl[e]), mr = __ballot(fr[e]);
-      const unsigned long long below = (1ull << lane) - 1;
-      rank[e] = (uint32_t)__popcll(ml & below) | ((uint32_t)__popcll(mr & below) << 16);
-      if (lane == 0)
-        wave_total[trip & 1][e * (kBigWG / 64) + wave] = (uint32_t)__popcll(ml) | ((uint32_t)__popcll(mr) << 16);
-    }
-    __syncthreads();
-    // exclusive prefix over the 64 (sub-trip, wave) totals, in position order, by every wave
-    uint32_t t = wave_total[trip & 1][lane], incl = t;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = __shfl_up(incl, off);
-      if (lane >= off) incl += up;
-    }
-    const uint32_t excl = incl - t;
-    for (int e = 0; e < kBigE; e++) {
-      const uint32_t before = __shfl(excl, e * (kBigWG / 64) + wave) + rank[e];
-      const int p = first + c0 + e * kBigWG + tid;
-      if (fl[e]) PL[first + base_l + (int)(before & 0xffffu)] = (uint32_t)p;
-      if (fr[e]) PR[first + base_r + (int)(before >> 16)] = (uint32_t)p;
-    }
-    const uint32_t all = __shfl(incl, 63);
-    base_l += (int)(all & 0xffffu);
-    base_r += (int)(all >> 16);
+  // exclusive prefix over the 64 (sub-trip, wave) totals, in position order, by every wave
+  const uint32_t own = wave_total[lane];
+  uint32_t incl = own;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
   }
+  const uint32_t excl = incl - own;
+  for (int e = 0; e < kBigE; e++) {
+    const uint32_t before = __shfl(excl, e * (kBigWG / 64) + wave) + rank[e];
+    const uint32_t p = (uint32_t)(first + t * kTile + e * kBigWG + tid);
+    if ((fl.left >> e) & 1) PL[first + (int)base_l + (int)(before & 0xffffu)] = p;
+    if ((fl.right >> e) & 1) PR[first + (int)base_r + (int)(before >> 16)] = p;
+  }
+}
+
+// PR holds the right candidates left to right: the k-th from the right is PR[first + cr - 1 - k]
+__global__ void __launch_bounds__(kBigWG)
+k_tb_swap(BigRange *list, int count, float *key, uint32_t *idx, const uint32_t *tile_counts,
+          const uint32_t *PL, const uint32_t *PR) {
+  __shared__ int s_range;
+  __shared__ uint32_t s_sum[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_range = range_of_tile(list, count, blockIdx.x);
   __syncthreads();
-  // PR holds the right candidates left to right: the k-th from the right is PR[first + cr - 1 - k]
-  const int cl = base_l, cr = base_r, m = cl < cr ? cl : cr;
-  for (int k0 = tid; k0 < m; k0 += kBigWG) {
+  const BigRange rg = list[s_range];
+  const int t = blockIdx.x - rg.tile_base, first = rg.f + 1;
+  const int tiles = (rg.l - first + kTile - 1) / kTile;
+  uint32_t ucl, ucr;
+  sum_tiles(tile_counts, rg.tile_base, rg.tile_base + tiles, s_sum, ucl, ucr);
+  const int cl = (int)ucl, cr = (int)ucr, m = cl < cr ? cl : cr;
+  if (t == 0 && tid == 0) list[s_range].cl = cl, list[s_range].cr = cr;
+  for (int e = 0; e < kBigE; e++) {
+    const int k0 = t * kTile + e * kBigWG + tid;
+    if (k0 >= m) break;
     const uint32_t a = PL[first + k0], b = PR[first + cr - 1 - k0];
     const bool sw = a < b;
     if (sw) {
@@ -311,24 +417,29 @@ k_tb_partition(const QsRange *in, uint32_t *idx, float *key, uint32_t *PL, uint3
       key[a] = kb, key[b] = ka, idx[a] = ib, idx[b] = ia;
     }
     const bool next = (k0 + 1 < m) && PL[first + k0 + 1] < PR[first + cr - 2 - k0];
-    if (sw && !next) sK = k0 + 1;
+    if (sw && !next) list[s_range].K = k0 + 1;  // the last swap; K stays 0 when there is none
   }
-  __syncthreads();
-  if (tid == 0) {
-    const int K = sK;
-    uint32_t cut = 0xffffffffu;
-    if (K < cl) cut = PL[first + K];
-    if (K >= 1) {
-      const uint32_t r = PR[first + cr - K];
-      cut = r < cut ? r : cut;
-    }
-    const int c = (int)cut, d = rg.depth - 1;
-    const int parts[2][2] = {{c, l}, {f, c}};
-    for (int h = 0; h < 2; h++) {
-      const int size = parts[h][1] - parts[h][0];
-      if (size > kT) push_range(big, n_big, parts[h][0], parts[h][1], d);
-      else if (size >= 2) push_range(small, n_small, parts[h][0], parts[h][1], d);
-    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tb_finish(const BigRange *list, int count, int to, SortQueues q, float *key, uint32_t *idx,
+            const uint32_t *PL, const uint32_t *PR) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= count) return;
+  const BigRange rg = list[r];
+  const int first = rg.f + 1, K = rg.K;
+  uint32_t cut = 0xffffffffu;  // min(L_{K+1}, R_K)
+  if (K < rg.cl) cut = PL[first + K];
+  if (K >= 1) {
+    const uint32_t rk = PR[first + rg.cr - K];
+    cut = rk < cut ? rk : cut;
+  }
+  const int c = (int)cut, d = rg.depth - 1;
+  const int parts[2][2] = {{c, rg.l}, {rg.f, c}};
+  for (int h = 0; h < 2; h++) {
+    const int size = parts[h][1] - parts[h][0];
+    if (size > kT) push_big(q, to, GlobalRecords{key, idx}, parts[h][0], parts[h][1], d);
+    else if (size >= 2) push_small(q, parts[h][0], parts[h][1], d);
   }
 }
 
@@ -521,14 +632,14 @@ k_tb_sort_small(const QsRange *list, uint32_t *idx, const float *key) {
 
 // The whole subtree under range kb of level Ls (at most kT objects), level by level in LDS.
 __global__ void __launch_bounds__(kWG)
-k_tb_subtree(int n, int Ls, int Lc, uint32_t *idx, const float *box, NodeOut out, uint32_t *root_order) {
+k_tb_subtree(int n, int Ls, uint32_t *idx, const float *box, NodeOut out, uint32_t *root_order) {
   __shared__ LdsSort S;
   __shared__ uint32_t gid[kT];                // object of a slot; S.idx holds slots
   __shared__ uint8_t axis_of[kT];             // by range start
   __shared__ unsigned long long planes[6][64];
   const int kb = blockIdx.x, tid = threadIdx.x;
-  int LO, m;
-  range_of_index(n, Ls, kb, LO, m);
+  int LO, m, root_id;
+  range_of_index(n, Ls, kb, LO, m, root_id);
   for (int p = tid; p < m; p += kWG) {
     gid[p] = idx[LO + p];
     S.idx[p] = p;
@@ -549,8 +660,8 @@ k_tb_subtree(int n, int Ls, int Lc, uint32_t *idx, const float *box, NodeOut out
       for (int i = tid; i < 6 * 64; i += kWG) planes[i / 64][i % 64] = i < 3 * 64 ? kMinIdentity : kMaxIdentity;
       __syncthreads();
       for (int p = tid; p < m; p += kWG) {
-        int k, lo, s;
-        subrange_of_position(m, j, p, k, lo, s);
+        int k, lo, s, rel;
+        subrange_of_position(m, j, p, k, lo, s, rel);
         const uint32_t o = gid[S.idx[p]];
         for (int a = 0; a < 3; a++) {
           atomicMin(&planes[a][k], pack_min(box[(size_t)a * n + o], (uint32_t)p));
@@ -561,8 +672,8 @@ k_tb_subtree(int n, int Ls, int Lc, uint32_t *idx, const float *box, NodeOut out
     }
     // range heads: the node's record and the sort axis
     for (int p = tid; p < m; p += kWG) {
-      int k, lo, s;
-      if (!subrange_of_position(m, j, p, k, lo, s) || p != lo) continue;
+      int k, lo, s, rel;
+      if (!subrange_of_position(m, j, p, k, lo, s, rel) || p != lo) continue;
       float bl[3], bh[3];
       if (by_atomics) {
         for (int a = 0; a < 3; a++) bl[a] = unpack_plane(planes[a][k]), bh[a] = unpack_plane(planes[3 + a][k]);
@@ -578,24 +689,22 @@ k_tb_subtree(int n, int Ls, int Lc, uint32_t *idx, const float *box, NodeOut out
           }
         }
       }
-      const int kg = (kb << j) | k, log = LO + lo;
-      const int id = node_number(L, Lc, kg, log);
+      const int id = root_id + rel;
       for (int a = 0; a < 3; a++) out.bmin[a][id] = bl[a], out.bmax[a][id] = bh[a];
       if (s == 1) {
         out.left[id] = -1, out.right[id] = -1;
         out.object[id] = (int32_t)gid[S.idx[p]];
         axis_of[p] = 3;
       } else {
-        const int lc = left_child_number(L, Lc, kg, log);
-        out.left[id] = lc, out.right[id] = lc + 1;
+        out.left[id] = id + 1, out.right[id] = id + 2 * (s >> 1);
         out.object[id] = -1;
         axis_of[p] = (uint8_t)longest_axis(bl, bh);
       }
     }
     __syncthreads();
     for (int p = tid; p < m; p += kWG) {
-      int k, lo, s;
-      const bool alive = subrange_of_position(m, j, p, k, lo, s);
+      int k, lo, s, rel;
+      const bool alive = subrange_of_position(m, j, p, k, lo, s, rel);
       if (!alive || s == 1) {
         S.start[p] = (uint16_t)p, S.end[p] = (uint16_t)(p + 1), S.depth[p] = kFinal;
         continue;
@@ -636,20 +745,28 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
     if (!obj_bmin[a] || !obj_bmax[a] || !node_bmin[a] || !node_bmax[a])
       return rtr::fail_msg(RTR_ERR_INVALID, "rtr_build_bvh: null array");
   const int n = n_objects, n_nodes = 2 * n - 1;
-  int Lc = 0, Ls = 0;
-  while ((2 << Lc) <= n) Lc++;                               // floor(log2 n)
+  int Ls = 0;
   while (((n + (1 << Ls) - 1) >> Ls) > kT) Ls++;             // first level whose ranges fit a workgroup
   int rc = RTR_OK;
   float *d_box = nullptr, *d_key = nullptr, *d_nodes = nullptr;
   uint32_t *d_idx = nullptr, *d_pl = nullptr, *d_pr = nullptr, *d_root = nullptr, *d_flags = nullptr;
   int32_t *d_links = nullptr;
   unsigned long long *d_planes = nullptr;
-  QsRange *d_list[3] = {nullptr, nullptr, nullptr};  // two lists of large ranges (in, out), one of small ones
-  int *d_counts = nullptr;                           // [0], [1]: large lists; [2]: small list
-  int h_counts[3];
+  SortQueues q;
+  memset(&q, 0, sizeof(q));
   NodeOut out;
   const size_t list_cap = (size_t)n / 2 + 2;
   const int grid_n = (n + 255) / 256;
+  // RTR_TREE_TIMES=1: where the call's time goes, on stderr (a development aid)
+  const bool times = getenv("RTR_TREE_TIMES") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!times) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "rtr_build_bvh %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   if (hipSetDevice(device) != hipSuccess) return rtr::fail_msg(RTR_ERR_DEVICE, "rtr_build_bvh: no such device");
   TB_TRY(hipMalloc((void **)&d_box, sizeof(float) * 6 * n));
   TB_TRY(hipMalloc((void **)&d_key, sizeof(float) * n));
@@ -666,6 +783,7 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
     out.bmax[a] = d_nodes + (size_t)(3 + a) * n_nodes;
   }
   out.left = d_links, out.right = d_links + n_nodes, out.object = d_links + 2 * (size_t)n_nodes;
+  mark("alloc+upload");
   k_tb_init<<<grid_n, 256>>>(n, d_box, d_idx, d_flags);
   {
     uint32_t bad = 0;
@@ -679,36 +797,48 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
     TB_TRY(hipMalloc((void **)&d_pl, sizeof(uint32_t) * n));
     TB_TRY(hipMalloc((void **)&d_pr, sizeof(uint32_t) * n));
     TB_TRY(hipMalloc((void **)&d_planes, sizeof(unsigned long long) * 6 * ((size_t)1 << (Ls - 1))));
-    for (int i = 0; i < 3; i++) TB_TRY(hipMalloc((void **)&d_list[i], sizeof(QsRange) * list_cap));
-    TB_TRY(hipMalloc((void **)&d_counts, sizeof(int) * 3));
+    const size_t big_cap = (size_t)n / kT + 2, tile_cap = (size_t)n / kTile + big_cap;
+    for (int i = 0; i < 2; i++) TB_TRY(hipMalloc((void **)&q.big[i], sizeof(BigRange) * big_cap));
+    TB_TRY(hipMalloc((void **)&q.big_count, sizeof(unsigned long long) * 2));
+    TB_TRY(hipMalloc((void **)&q.small, sizeof(QsRange) * list_cap));
+    TB_TRY(hipMalloc((void **)&q.small_count, sizeof(int)));
+    TB_TRY(hipMalloc((void **)&q.tile_counts, sizeof(uint32_t) * tile_cap));
   }
   for (int L = 0; L < Ls; L++) {
     const int ranges = 1 << L;
     k_tb_fill64<<<(6 * ranges + 255) / 256, 256>>>(d_planes, 3 * ranges, 6 * ranges);
-    k_tb_level_boxes<<<grid_n, 256>>>(n, L, d_idx, d_box, d_planes);
-    TB_TRY(hipMemsetAsync(d_counts, 0, sizeof(int) * 3, 0));
-    k_tb_level_keys<<<grid_n, 256>>>(n, L, Lc, d_idx, d_box, d_planes, d_key, out, d_list[0], d_counts,
-                                     d_list[2], d_counts + 2);
+    k_tb_level_boxes<<<(n + kBoxWG - 1) / kBoxWG, kBoxWG>>>(n, L, d_idx, d_box, d_planes);
+    TB_TRY(hipMemsetAsync(q.big_count, 0, sizeof(unsigned long long) * 2, 0));
+    TB_TRY(hipMemsetAsync(q.small_count, 0, sizeof(int), 0));
+    k_tb_level_keys<<<grid_n, 256>>>(n, L, d_idx, d_box, d_planes, d_key, out);
+    k_tb_level_ranges<<<(ranges + 255) / 256, 256>>>(n, L, q, d_idx, d_key);
     int cur = 0;
     for (int round = 0;; round++) {
-      TB_TRY(hipMemcpy(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost));
-      const int n_in = h_counts[cur];
-      if (n_in == 0) break;
+      unsigned long long queued = 0;
+      TB_TRY(hipMemcpy(&queued, q.big_count + cur, sizeof(queued), hipMemcpyDeviceToHost));
+      const int n_ranges = (int)(queued >> 32), n_tiles = (int)(queued & 0xffffffffu);
+      if (n_ranges == 0) break;
       if (round > 2 * 26 + 2) {
         rc = rtr::fail_msg(RTR_ERR_DEVICE, "rtr_build_bvh: the sort did not end within its depth budget");
         goto done;
       }
-      k_tb_partition<<<n_in, kBigWG>>>(d_list[cur], d_idx, d_key, d_pl, d_pr, d_list[1 - cur],
-                                       d_counts + (1 - cur), d_list[2], d_counts + 2);
-      TB_TRY(hipMemsetAsync(d_counts + cur, 0, sizeof(int), 0));
+      TB_TRY(hipMemsetAsync(q.big_count + (1 - cur), 0, sizeof(unsigned long long), 0));
+      k_tb_count<<<n_tiles, kBigWG>>>(q.big[cur], n_ranges, d_key, q.tile_counts);
+      k_tb_scatter<<<n_tiles, kBigWG>>>(q.big[cur], n_ranges, d_key, q.tile_counts, d_pl, d_pr);
+      k_tb_swap<<<n_tiles, kBigWG>>>(q.big[cur], n_ranges, d_key, d_idx, q.tile_counts, d_pl, d_pr);
+      k_tb_finish<<<(n_ranges + 255) / 256, 256>>>(q.big[cur], n_ranges, 1 - cur, q, d_key, d_idx, d_pl, d_pr);
       cur = 1 - cur;
     }
-    if (h_counts[2] > 0) k_tb_sort_small<<<h_counts[2], kWG>>>(d_list[2], d_idx, d_key);
+    int n_small = 0;
+    TB_TRY(hipMemcpy(&n_small, q.small_count, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_small > 0) k_tb_sort_small<<<n_small, kWG>>>(q.small, d_idx, d_key);
     if (L == 0) TB_TRY(hipMemcpyAsync(d_root, d_idx, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, 0));
   }
-  k_tb_subtree<<<1 << Ls, kWG>>>(n, Ls, Lc, d_idx, d_box, out, d_root);
+  mark("upper levels");
+  k_tb_subtree<<<1 << Ls, kWG>>>(n, Ls, d_idx, d_box, out, d_root);
   TB_TRY(hipGetLastError());
   TB_TRY(hipDeviceSynchronize());
+  mark("subtrees");
   for (int a = 0; a < 3; a++) {
     TB_TRY(hipMemcpy(node_bmin[a], out.bmin[a], sizeof(float) * n_nodes, hipMemcpyDeviceToHost));
     TB_TRY(hipMemcpy(node_bmax[a], out.bmax[a], sizeof(float) * n_nodes, hipMemcpyDeviceToHost));
@@ -717,10 +847,12 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
   TB_TRY(hipMemcpy(node_right, out.right, sizeof(int32_t) * n_nodes, hipMemcpyDeviceToHost));
   TB_TRY(hipMemcpy(node_object, out.object, sizeof(int32_t) * n_nodes, hipMemcpyDeviceToHost));
   if (root_order) TB_TRY(hipMemcpy(root_order, d_root, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  mark("download");
 done:
   (void)hipFree(d_box), (void)hipFree(d_key), (void)hipFree(d_idx), (void)hipFree(d_root);
   (void)hipFree(d_nodes), (void)hipFree(d_links), (void)hipFree(d_flags), (void)hipFree(d_pl);
-  (void)hipFree(d_pr), (void)hipFree(d_planes), (void)hipFree(d_counts);
-  for (int i = 0; i < 3; i++) (void)hipFree(d_list[i]);
+  (void)hipFree(d_pr), (void)hipFree(d_planes), (void)hipFree(q.big[0]), (void)hipFree(q.big[1]);
+  (void)hipFree(q.big_count), (void)hipFree(q.small), (void)hipFree(q.small_count), (void)hipFree(q.tile_counts);
+  mark("free");
   return rc;
 }

@@ -13,6 +13,7 @@
 #include <iostream>
 #include <limits>
 #include <map>
+#include <new>
 #include <stdexcept>
 #include <thread>
 
@@ -81,6 +82,19 @@ Trangle::Trangle(Material *_material, Vector3f _p0, Vector3f _p1, Vector3f _p2, 
   bound = Bound3(Vector3f(min3(p0.x, p1.x, p2.x), min3(p0.y, p1.y, p2.y), min3(p0.z, p1.z, p2.z)),
                  Vector3f(max3(p0.x, p1.x, p2.x), max3(p0.y, p1.y, p2.y), max3(p0.z, p1.z, p2.z)));
   area = faceCross.getLen();  // twice the geometric area, as in the reference
+}
+
+// fn(from, to) over [0, count) in contiguous pieces, on several threads when the range is large
+template <class F>
+static void parallel_ranges(size_t count, F fn) {
+  unsigned workers = std::thread::hardware_concurrency();
+  if (workers > 16) workers = 16;
+  if (count < (1u << 15) || workers < 2) return fn((size_t)0, count);
+  std::vector<std::future<void>> parts;
+  for (unsigned w = 0; w < workers; w++)
+    parts.push_back(std::async(std::launch::async, fn, count * w / workers, count * (w + 1) / workers));
+  for (auto &part : parts) part.wait();
+  for (auto &part : parts) part.get();
 }
 
 // ---------------- BVH (src/BVH.cpp:19-64) ----------------
@@ -171,9 +185,9 @@ size_t BVH::deviceMin = 1 << 13;
 int BVH::buildDevice = 0;
 
 void BVH::clear() {
-  if (arena.empty()) destroy(root);
-  arena.clear();
-  arena.shrink_to_fit();
+  if (arena) free(arena);  // BVHNode has no destructor to run
+  else destroy(root);
+  arena = nullptr;
   root = nullptr;
 }
 
@@ -181,32 +195,51 @@ void BVH::clear() {
 // come back (numbered level by level, node 0 the root) and become BVHNodes in one block.
 BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
   const size_t n = objs.size(), nn = 2 * n - 1;
+  const bool times = getenv("RTR_TREE_TIMES") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!times) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "BVH::buildOnDevice %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   std::vector<float> ob[6], nb[6];
   for (int a = 0; a < 6; a++) ob[a].resize(n), nb[a].resize(nn);
-  for (size_t k = 0; k < n; k++) {
-    const Bound3 b = objs[k]->getBound();
-    ob[0][k] = b.min.x, ob[1][k] = b.min.y, ob[2][k] = b.min.z;
-    ob[3][k] = b.max.x, ob[4][k] = b.max.y, ob[5][k] = b.max.z;
-  }
+  parallel_ranges(n, [&](size_t from, size_t to) {
+    for (size_t k = from; k < to; k++) {
+      const Bound3 b = objs[k]->getBound();
+      ob[0][k] = b.min.x, ob[1][k] = b.min.y, ob[2][k] = b.min.z;
+      ob[3][k] = b.max.x, ob[4][k] = b.max.y, ob[5][k] = b.max.z;
+    }
+  });
   std::vector<int32_t> left(nn), right(nn), object(nn), order(n);
   const float *omin[3] = {ob[0].data(), ob[1].data(), ob[2].data()};
   const float *omax[3] = {ob[3].data(), ob[4].data(), ob[5].data()};
   float *nmin[3] = {nb[0].data(), nb[1].data(), nb[2].data()};
   float *nmax[3] = {nb[3].data(), nb[4].data(), nb[5].data()};
+  mark("boxes");
   if (rtr_build_bvh(buildDevice, (int32_t)n, omin, omax, nmin, nmax, left.data(), right.data(),
                     object.data(), order.data()) != RTR_OK)
     throw std::runtime_error(std::string("rtr_build_bvh: ") + rtr_last_error());
-  arena.resize(nn);
-  for (size_t i = 0; i < nn; i++) {
-    BVHNode &node = arena[i];
-    node.bound = Bound3(Vector3f(nb[0][i], nb[1][i], nb[2][i]), Vector3f(nb[3][i], nb[4][i], nb[5][i]));
-    node.left = left[i] >= 0 ? &arena[left[i]] : nullptr;
-    node.right = right[i] >= 0 ? &arena[right[i]] : nullptr;
-    node.object = object[i] >= 0 ? objs[object[i]] : nullptr;
-  }
+  mark("rtr_build_bvh");
+  // raw storage, first touched by the threads that fill it
+  arena = static_cast<BVHNode *>(malloc(nn * sizeof(BVHNode)));
+  if (!arena) throw std::bad_alloc();
+  parallel_ranges(nn, [&](size_t from, size_t to) {
+    for (size_t i = from; i < to; i++) {
+      BVHNode &node = *new (&arena[i]) BVHNode();
+      node.bound = Bound3(Vector3f(nb[0][i], nb[1][i], nb[2][i]), Vector3f(nb[3][i], nb[4][i], nb[5][i]));
+      node.left = left[i] >= 0 ? &arena[left[i]] : nullptr;
+      node.right = right[i] >= 0 ? &arena[right[i]] : nullptr;
+      node.object = object[i] >= 0 ? objs[object[i]] : nullptr;
+    }
+  });
   std::vector<Object *> sorted(n);
-  for (size_t k = 0; k < n; k++) sorted[k] = objs[order[k]];
+  parallel_ranges(n, [&](size_t from, size_t to) {
+    for (size_t k = from; k < to; k++) sorted[k] = objs[order[k]];
+  });
   objs.swap(sorted);
+  mark("nodes");
   return &arena[0];
 }
 
@@ -242,24 +275,31 @@ TrangleMesh::TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
   const std::vector<unsigned int> &I = *_posIndices;
   trangles.resize(I.size() / 3);
   area = 0;
-  for (size_t k = 0; k < I.size(); k += 3) {
-    const unsigned a = I[k], b = I[k + 1], c = I[k + 2];
-    if (a >= P.size() || b >= P.size() || c >= P.size())
-      throw std::out_of_range("TrangleMesh: vertex index out of range");
-    Vector3f n(0);
-    Vector2f uv[3];
-    if (_normals) n = (*_normals)[a] + (*_normals)[b] + (*_normals)[c];
-    if (_textureCoords) {
-      uv[0] = (*_textureCoords)[a];
-      uv[1] = (*_textureCoords)[b];
-      uv[2] = (*_textureCoords)[c];
+  for (size_t k = 0; k < I.size(); k++)
+    if (I[k] >= P.size()) throw std::out_of_range("TrangleMesh: vertex index out of range");
+  // The triangles do not depend on one another: large meshes construct them on several threads.
+  // The mesh's area is summed afterwards, in index order, as the reference's loop does
+  // (include/Trangle.h:79-91).
+  const size_t count = I.size() / 3;
+  auto construct = [&](size_t from, size_t to) {
+    for (size_t f = from; f < to; f++) {
+      const unsigned a = I[3 * f], b = I[3 * f + 1], c = I[3 * f + 2];
+      Vector3f n(0);
+      Vector2f uv[3];
+      if (_normals) n = (*_normals)[a] + (*_normals)[b] + (*_normals)[c];
+      if (_textureCoords) {
+        uv[0] = (*_textureCoords)[a];
+        uv[1] = (*_textureCoords)[b];
+        uv[2] = (*_textureCoords)[c];
+      }
+      // without normals this passes normalize(0) = NaN, which selects the face normal
+      Trangle *t = new Trangle(_material, P[a], P[b], P[c], n.normalize(), uv[0], uv[1], uv[2]);
+      t->indexInMesh = (int)f;
+      trangles[f] = t;
     }
-    // without normals this passes normalize(0) = NaN, which selects the face normal
-    Trangle *t = new Trangle(_material, P[a], P[b], P[c], n.normalize(), uv[0], uv[1], uv[2]);
-    t->indexInMesh = (int)(k / 3);
-    area += t->getArea();
-    trangles[k / 3] = t;
-  }
+  };
+  parallel_ranges(count, construct);
+  for (size_t f = 0; f < count; f++) area += trangles[f]->getArea();
   bvh = new BVH();
   bvh->buildBVH(trangles);
   if (!trangles.empty()) bound = bvh->getBound();
@@ -360,67 +400,124 @@ struct Flattener {
   }
 
   void add_mesh(const TrangleMesh *m) {
-    std::vector<const Trangle *> leaf_order;
-    collect_triangles(m->getBVH()->getRoot(), leaf_order);
-    std::vector<const Trangle *> by_index(leaf_order.size(), nullptr);
-    for (const Trangle *t : leaf_order) by_index[t->indexInMesh] = t;
-    int mat = material_id(m->getMaterial());
-    mesh_base[m] = (int)f.prim_kind.size();
-    for (const Trangle *t : by_index) {  // prim ids follow the index-triple order
-      f.prim_kind.push_back(RTR_PRIM_TRIANGLE);
-      f.prim_index.push_back((int)f.tri_area.size());
-      f.prim_material.push_back(mat);
-      f.prim_object.push_back(const_cast<Trangle *>(t));
-      const Vector3f *p[3] = {&t->P0(), &t->P1(), &t->P2()};
-      std::vector<float> *dst[3] = {f.tri_p0, f.tri_p1, f.tri_p2};
-      for (int v = 0; v < 3; v++) {
-        dst[v][0].push_back(p[v]->x);
-        dst[v][1].push_back(p[v]->y);
-        dst[v][2].push_back(p[v]->z);
-      }
-      f.tri_n[0].push_back(t->getNormal().x);
-      f.tri_n[1].push_back(t->getNormal().y);
-      f.tri_n[2].push_back(t->getNormal().z);
-      f.tri_area.push_back(t->getArea());
+    // prim ids follow the index-triple order; every triangle knows its place in it
+    const std::vector<Object *> &tris = m->getTrangles();
+    const size_t count = tris.size(), prim0 = f.prim_kind.size(), row0 = f.tri_area.size();
+    const int mat = material_id(m->getMaterial());
+    mesh_base[m] = (int)prim0;
+    f.prim_kind.resize(prim0 + count, RTR_PRIM_TRIANGLE);
+    f.prim_index.resize(prim0 + count);
+    f.prim_material.resize(prim0 + count, mat);
+    f.prim_object.resize(prim0 + count);
+    f.tri_area.resize(row0 + count);
+    for (int a = 0; a < 3; a++) {
+      f.tri_p0[a].resize(row0 + count), f.tri_p1[a].resize(row0 + count);
+      f.tri_p2[a].resize(row0 + count), f.tri_n[a].resize(row0 + count);
     }
+    parallel_ranges(count, [&](size_t from, size_t to) {
+      for (size_t k = from; k < to; k++) {
+        const Trangle *t = static_cast<const Trangle *>(tris[k]);
+        const size_t i = (size_t)t->indexInMesh, row = row0 + i;
+        f.prim_index[prim0 + i] = (int)row;
+        f.prim_object[prim0 + i] = const_cast<Trangle *>(t);
+        const Vector3f *p[3] = {&t->P0(), &t->P1(), &t->P2()};
+        std::vector<float> *dst[3] = {f.tri_p0, f.tri_p1, f.tri_p2};
+        for (int v = 0; v < 3; v++) dst[v][0][row] = p[v]->x, dst[v][1][row] = p[v]->y, dst[v][2][row] = p[v]->z;
+        f.tri_n[0][row] = t->getNormal().x, f.tri_n[1][row] = t->getNormal().y, f.tri_n[2][row] = t->getNormal().z;
+        f.tri_area[row] = t->getArea();
+      }
+    });
   }
 
-  // `mesh` is the mesh whose nested tree n belongs to, null in the top-level tree
-  int add_node(const BVHNode *n, const Object *mesh = nullptr) {
-    // a mesh leaf of the top-level tree is replaced by the mesh's own tree: its
-    // root carries the same bound (include/Trangle.h:56), so the second box test
-    // the reference performs there cannot change the outcome
-    if (n->object && n->object->kind() == Object::MESH) {
-      const BVHNode *inner = static_cast<const TrangleMesh *>(n->object)->getBVH()->getRoot();
-      if (inner) return add_node(inner, n->object);
+  // One entry per node that the walk below visits.
+  struct Visit {
+    const BVHNode *node;
+    const Object *mesh;  // the mesh whose nested tree the node belongs to, null in the top-level tree
+    int id, right;       // its number; number of the right child, -1 for a leaf
+  };
+  // A mesh whose tree is one block of nodes in depth-first order already (built on the device):
+  // its nodes take consecutive numbers and are copied without a walk.
+  struct Block {
+    const BVHNode *nodes;
+    const Object *mesh;
+    int first, count;
+  };
+
+  // Numbers the nodes depth first, left child first, with an explicit stack, then fills the arrays
+  // on several threads.  A mesh leaf of the top-level tree is replaced by the mesh's own tree: its
+  // root carries the same bound (include/Trangle.h:56), so the second box test the reference
+  // performs there cannot change the outcome.
+  void add_tree(const BVHNode *root) {
+    std::vector<Visit> order;
+    std::vector<Block> blocks;
+    struct Pending {
+      const BVHNode *node;
+      const Object *mesh;
+      int parent;  // entry of `order` whose right child this is, -1: none
+    };
+    std::vector<Pending> stack{{root, nullptr, -1}};
+    int next_id = 0;
+    while (!stack.empty()) {
+      Pending at = stack.back();
+      stack.pop_back();
+      const int id = next_id;
+      if (at.parent >= 0) order[at.parent].right = id;
+      if (!at.mesh && at.node->object && at.node->object->kind() == Object::MESH) {
+        const TrangleMesh *m = static_cast<const TrangleMesh *>(at.node->object);
+        const BVHNode *inner = m->getBVH()->getRoot();
+        if (inner && m->getBVH()->preorderBlock()) {
+          const int count = 2 * (int)m->numTrangles() - 1;
+          blocks.push_back(Block{inner, m, id, count});
+          next_id += count;
+          continue;
+        }
+        if (inner) at.mesh = m, at.node = inner;
+      }
+      next_id++;
+      order.push_back(Visit{at.node, at.mesh, id, -1});
+      if (!at.node->object) {
+        stack.push_back(Pending{at.node->right, at.mesh, (int)order.size() - 1});
+        stack.push_back(Pending{at.node->left, at.mesh, -1});
+      }
     }
-    int id = (int)f.node_prim.size();
-    const float lo[3] = {n->bound.min.x, n->bound.min.y, n->bound.min.z};
-    const float hi[3] = {n->bound.max.x, n->bound.max.y, n->bound.max.z};
-    for (int a = 0; a < 3; a++) {
-      f.node_bmin[a].push_back(lo[a]);
-      f.node_bmax[a].push_back(hi[a]);
+    const size_t count = (size_t)next_id;
+    for (int a = 0; a < 3; a++) f.node_bmin[a].resize(count), f.node_bmax[a].resize(count);
+    f.node_left.resize(count), f.node_right.resize(count), f.node_prim.resize(count);
+    auto put = [&](size_t id, const BVHNode *n, const Object *mesh, int left, int right) {
+      f.node_bmin[0][id] = n->bound.min.x, f.node_bmin[1][id] = n->bound.min.y, f.node_bmin[2][id] = n->bound.min.z;
+      f.node_bmax[0][id] = n->bound.max.x, f.node_bmax[1][id] = n->bound.max.y, f.node_bmax[2][id] = n->bound.max.z;
+      f.node_left[id] = left, f.node_right[id] = right;
+      f.node_prim[id] = !n->object ? -1
+                        : mesh     ? triangle_prim(mesh, static_cast<const Trangle *>(n->object))
+                                   : prim_of.at(n->object);
+    };
+    parallel_ranges(order.size(), [&](size_t from, size_t to) {
+      for (size_t k = from; k < to; k++) {
+        const Visit &v = order[k];
+        put((size_t)v.id, v.node, v.mesh, v.node->object ? -1 : v.id + 1, v.right);
+      }
+    });
+    for (const Block &b : blocks) {
+      const int base = mesh_base.at(b.mesh);
+      parallel_ranges((size_t)b.count, [&](size_t from, size_t to) {
+        for (size_t i = from; i < to; i++) {
+          const BVHNode *n = b.nodes + i;
+          const size_t id = (size_t)b.first + i;
+          f.node_bmin[0][id] = n->bound.min.x, f.node_bmin[1][id] = n->bound.min.y, f.node_bmin[2][id] = n->bound.min.z;
+          f.node_bmax[0][id] = n->bound.max.x, f.node_bmax[1][id] = n->bound.max.y, f.node_bmax[2][id] = n->bound.max.z;
+          f.node_left[id] = n->left ? b.first + (int)(n->left - b.nodes) : -1;
+          f.node_right[id] = n->right ? b.first + (int)(n->right - b.nodes) : -1;
+          f.node_prim[id] = n->object ? base + static_cast<const Trangle *>(n->object)->indexInMesh : -1;
+        }
+      });
     }
-    f.node_left.push_back(-1);
-    f.node_right.push_back(-1);
-    f.node_prim.push_back(-1);
-    if (n->object) {
-      f.node_prim[id] = mesh ? triangle_prim(mesh, static_cast<const Trangle *>(n->object))
-                             : prim_of.at(n->object);
-    } else {
-      int l = add_node(n->left, mesh);
-      int r = add_node(n->right, mesh);
-      f.node_left[id] = l;
-      f.node_right[id] = r;
-    }
-    return id;
   }
 };
 
 }  // namespace
 
 namespace {
-// the walk of Flattener::add_node, looking for flattened node `want`
+// the depth-first numbering of Flattener::add_tree, looking for flattened node `want`
 bool set_bound(BVHNode *n, int &next, int want, const Bound3 &b) {
   if (n->object && n->object->kind() == Object::MESH) {
     BVHNode *inner = const_cast<BVHNode *>(static_cast<const TrangleMesh *>(n->object)->getBVH()->getRoot());
@@ -498,7 +595,7 @@ const FlatScene &Scene::flatten() {
     else if (o->kind() == Object::MESH) fl.add_mesh(static_cast<TrangleMesh *>(o));
     else throw std::invalid_argument("Scene: only Sphere and TrangleMesh can be added");
   }
-  if (bvh->getRoot()) fl.add_node(bvh->getRoot());
+  if (bvh->getRoot()) fl.add_tree(bvh->getRoot());
   flat.light_tri_begin.push_back(0);
   for (Object *l : lights) {
     flat.light_area.push_back(l->getArea());

@@ -129,7 +129,7 @@ struct BVHNode {
 
 class BVH {
   BVHNode *root = nullptr;
-  std::vector<BVHNode> arena;  // the nodes of a tree that came from the device as arrays
+  BVHNode *arena = nullptr;  // one block holding the nodes of a tree that came from the device as arrays
   static BVHNode *build(std::vector<Object *> &objs);
   BVHNode *buildOnDevice(std::vector<Object *> &objs);
   static void destroy(BVHNode *n);
@@ -151,6 +151,8 @@ class BVH {
   void buildBVH(std::vector<Object *> &objs);
   Bound3 getBound() const { return root->bound; }
   const BVHNode *getRoot() const { return root; }
+  // non-null: the tree's nodes are one block in depth-first order, left child first (root at [0])
+  const BVHNode *preorderBlock() const { return arena; }
 };
 
 // ---- include/Sphere.h ----
@@ -194,6 +196,7 @@ class TrangleMesh : public Object {
   TrangleMesh &operator=(const TrangleMesh &) = delete;
   Kind kind() const override { return MESH; }
   size_t numTrangles() const { return trangles.size(); }
+  const std::vector<Object *> &getTrangles() const { return trangles; }
   const BVH *getBVH() const { return bvh; }
 };
 

@@ -88,8 +88,9 @@ def test_grid_meshes_with_tied_keys(rt, cells):
                                     (60000, "signed_zeros")])
 def test_sorts_that_depend_on_tie_order(rt, n, kind):
     """Key sequences that drive std::sort through its corners: all keys equal, sorted and reversed
-    input in runs of equal keys (these exhaust the depth budget and end in heap sorts), few distinct
-    values, zeros of both signs."""
+    input in runs of equal keys, few distinct values, zeros of both signs, and an organ pipe, which
+    exhausts the depth budget: 165 ranges of up to 19 682 keys end in heap sorts at the root alone
+    (counted with libstdc++'s own partition), in LDS and, for the large ones, in memory."""
     rng = np.random.default_rng(n)
     i = np.arange(n)
     keys = {"equal": np.full(n, 7.0),
@@ -122,6 +123,9 @@ def test_root_order_and_raw_arrays(rt):
     leaves = left < 0
     assert leaves.sum() == n and (right[leaves] < 0).all() and (obj[~leaves] < 0).all()
     assert sorted(obj[leaves]) == list(range(n)) and sorted(order) == list(range(n))
+    # depth-first numbering, left child first
+    inner = np.flatnonzero(~leaves)
+    assert (left[inner] == inner + 1).all() and (right[inner] > left[inner]).all()
     assert np.array_equal(nlo[0], lo.min(0)) and np.array_equal(nhi[0], hi.max(0))
     ext = nhi[0] - nlo[0]
     axis = 0 if ext[0] > ext[1] and ext[0] > ext[2] else (1 if ext[1] > ext[2] else 2)
