@@ -123,7 +123,7 @@ def mesh_case(torch, rt, scenes, dev, seed, n, render):
     t0 = time.perf_counter()
     spec = scenes.heightfield_spec(n)
     t1 = time.perf_counter()
-    sm = rt.HostScene.from_spec(spec)  # Scene::rebuildBVH of the host mirror: trees
+    sm = rt.HostScene.from_spec(spec)  # triangles (host objects) + trees (rtr_build_bvh on the device)
     t2 = time.perf_counter()
     sm.flatten_for_upload()            # pointer trees -> the arrays of rtr_scene_desc (host)
     t2b = time.perf_counter()
@@ -159,8 +159,9 @@ def mesh_case(torch, rt, scenes, dev, seed, n, render):
              else "hbm gather (scene larger than the Infinity Cache)")
     rec = {"workload": "default scene + %dx%d jittered height field (%d triangles, %.1f M tree nodes, %d MB of node and leaf records)"
                        % (n, n, n_tri, 2 * n_tri / 1e6, scene_mb),
-           "scene_ms": {"mesh_arrays": (t1 - t0) * 1e3, "host_trees": (t2 - t1) * 1e3,
-                        "host_flatten": (t2b - t2) * 1e3, "rtr_scene_create": (t3 - t2b) * 1e3},
+           "scene_ms": {"mesh_arrays": (t1 - t0) * 1e3, "objects_and_trees": (t2 - t1) * 1e3,
+                        "host_flatten": (t2b - t2) * 1e3, "rtr_scene_create": (t3 - t2b) * 1e3,
+                        "tree_builder": os.environ.get("RTR_TREE_BUILDER", "device (rtr_build_bvh)")},
            "trace": {"rays": nr, "mrays_per_s": nr / (ms * 1e-3) / 1e6, "ms_per_launch": ms,
                      "boxes_per_ray": boxes / nr, "triangles_per_ray": tris / nr,
                      "spheres_per_ray": sphs / nr,

@@ -203,7 +203,7 @@ BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
     fprintf(stderr, "BVH::buildOnDevice %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  std::vector<float> ob[6], nb[6];
+  BulkVector<float> ob[6], nb[6];
   for (int a = 0; a < 6; a++) ob[a].resize(n), nb[a].resize(nn);
   parallel_ranges(n, [&](size_t from, size_t to) {
     for (size_t k = from; k < to; k++) {
@@ -212,11 +212,19 @@ BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
       ob[3][k] = b.max.x, ob[4][k] = b.max.y, ob[5][k] = b.max.z;
     }
   });
-  std::vector<int32_t> left(nn), right(nn), object(nn), order(n);
+  BulkVector<int32_t> left(nn), right(nn), object(nn), order(n);
   const float *omin[3] = {ob[0].data(), ob[1].data(), ob[2].data()};
   const float *omax[3] = {ob[3].data(), ob[4].data(), ob[5].data()};
   float *nmin[3] = {nb[0].data(), nb[1].data(), nb[2].data()};
   float *nmax[3] = {nb[3].data(), nb[4].data(), nb[5].data()};
+  // first touch of the result arrays by several threads (the copy from the device would otherwise
+  // fault every page in on one)
+  parallel_ranges(nn, [&](size_t from, size_t to) {
+    for (size_t i = from; i < to; i += 1024) {
+      for (int a = 0; a < 6; a++) nb[a][i] = 0.f;
+      left[i] = right[i] = object[i] = 0;
+    }
+  });
   mark("boxes");
   if (rtr_build_bvh(buildDevice, (int32_t)n, omin, omax, nmin, nmax, left.data(), right.data(),
                     object.data(), order.data()) != RTR_OK)
@@ -281,6 +289,10 @@ TrangleMesh::TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
   // The mesh's area is summed afterwards, in index order, as the reference's loop does
   // (include/Trangle.h:79-91).
   const size_t count = I.size() / 3;
+  // one block for all triangles instead of one allocation each: a million small allocations from
+  // sixteen threads spend their time in the allocator and in page faults
+  block = static_cast<Trangle *>(malloc((count ? count : 1) * sizeof(Trangle)));
+  if (!block) throw std::bad_alloc();
   auto construct = [&](size_t from, size_t to) {
     for (size_t f = from; f < to; f++) {
       const unsigned a = I[3 * f], b = I[3 * f + 1], c = I[3 * f + 2];
@@ -293,7 +305,7 @@ TrangleMesh::TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
         uv[2] = (*_textureCoords)[c];
       }
       // without normals this passes normalize(0) = NaN, which selects the face normal
-      Trangle *t = new Trangle(_material, P[a], P[b], P[c], n.normalize(), uv[0], uv[1], uv[2]);
+      Trangle *t = new (block + f) Trangle(_material, P[a], P[b], P[c], n.normalize(), uv[0], uv[1], uv[2]);
       t->indexInMesh = (int)f;
       trangles[f] = t;
     }
@@ -307,7 +319,8 @@ TrangleMesh::TrangleMesh(Material *_material, std::vector<Vector3f> *_positions,
 
 TrangleMesh::~TrangleMesh() {
   delete bvh;
-  for (Object *t : trangles) delete t;
+  for (Object *t : trangles) static_cast<Trangle *>(t)->~Trangle();
+  free(block);
 }
 
 // ---------------- Scene (include/Scene.h:33-46) ----------------
@@ -421,7 +434,7 @@ struct Flattener {
         f.prim_index[prim0 + i] = (int)row;
         f.prim_object[prim0 + i] = const_cast<Trangle *>(t);
         const Vector3f *p[3] = {&t->P0(), &t->P1(), &t->P2()};
-        std::vector<float> *dst[3] = {f.tri_p0, f.tri_p1, f.tri_p2};
+        BulkVector<float> *dst[3] = {f.tri_p0, f.tri_p1, f.tri_p2};
         for (int v = 0; v < 3; v++) dst[v][0][row] = p[v]->x, dst[v][1][row] = p[v]->y, dst[v][2][row] = p[v]->z;
         f.tri_n[0][row] = t->getNormal().x, f.tri_n[1][row] = t->getNormal().y, f.tri_n[2][row] = t->getNormal().z;
         f.tri_area[row] = t->getArea();

@@ -16,7 +16,9 @@
 // vector.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtr.h"
@@ -185,6 +187,7 @@ class Trangle : public Object {
 
 class TrangleMesh : public Object {
   std::vector<Object *> trangles;  // re-ordered by the BVH build, like the reference's
+  Trangle *block = nullptr;        // the triangles themselves, one allocation for the whole mesh
   BVH *bvh;
 
  public:
@@ -207,18 +210,42 @@ struct Camera {
   Camera(Vector3f p, Vector3f f, Vector3f u, float _fov) : position(p), frontDir(f), upDir(u), fov(_fov) {}
 };
 
+// std::allocator whose resize() leaves trivial elements uninitialised: the large arrays below are
+// sized first and then filled by several threads, and zeroing them first (on one thread) costs as
+// much as filling them.
+template <class T>
+struct NoInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef NoInitAllocator<U> other;
+  };
+  NoInitAllocator() = default;
+  template <class U>
+  NoInitAllocator(const NoInitAllocator<U> &) {}
+  template <class U>
+  void construct(U *p) {
+    ::new (static_cast<void *>(p)) U;
+  }
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+  }
+};
+template <class T>
+using BulkVector = std::vector<T, NoInitAllocator<T>>;
+
 // The arrays of rtr_scene_desc, owned.
 struct FlatScene {
-  std::vector<float> node_bmin[3], node_bmax[3];
-  std::vector<int32_t> node_left, node_right, node_prim;
-  std::vector<int32_t> prim_kind, prim_index, prim_material;
-  std::vector<float> tri_p0[3], tri_p1[3], tri_p2[3], tri_n[3], tri_area;
+  BulkVector<float> node_bmin[3], node_bmax[3];
+  BulkVector<int32_t> node_left, node_right, node_prim;
+  BulkVector<int32_t> prim_kind, prim_index, prim_material;
+  BulkVector<float> tri_p0[3], tri_p1[3], tri_p2[3], tri_n[3], tri_area;
   std::vector<float> sph_c[3], sph_r, sph_area;
   std::vector<int32_t> mat_kind;
   std::vector<float> mat_emission[3], mat_kd[3], mat_ks[3], mat_ior, mat_roughness;
   std::vector<int32_t> light_kind, light_prim, light_tri_begin, light_tris;
   std::vector<float> light_area;
-  std::vector<Object *> prim_object;  // prim id -> Sphere* / Trangle*
+  BulkVector<Object *> prim_object;  // prim id -> Sphere* / Trangle*
   rtr_scene_desc desc() const;
 };
 
