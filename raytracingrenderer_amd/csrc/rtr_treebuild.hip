@@ -55,7 +55,7 @@ int fail_msg(int code, const std::string &msg);  // rtr_api.hip: sets rtr_last_e
 namespace {
 
 constexpr int kT = 2048;          // objects a workgroup sorts in LDS
-constexpr int kWG = 256;          // its lanes
+constexpr int kWG = 1024;         // its lanes
 constexpr int kEPL = kT / kWG;    // consecutive positions per lane in the scan step
 constexpr int kBigWG = 1024;      // lanes of the workgroup that partitions one large range
 constexpr int kBigE = 4;          // positions per lane and trip there

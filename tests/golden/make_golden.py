@@ -14,6 +14,10 @@ outputs are data -- inputs and the reference's outputs -- never source text:
   lights_default.npz     Scene::samplingLight outputs + draws (default scene and a
                          multi-light scene with an emissive mesh)
   paths_default.npz      Render::pathTracing radiance for (ray, seed) pairs + the draws
+  tree_tied_keys.npz     BVH::selfBuildBVH of a 72 x 72 height field over a regular grid (10 368 triangles whose
+                         box centres tie along whole rows): the leaf of every node in depth-first order (which
+                         fixes the topology, tie order of the reference's std::sort included), the children,
+                         and the boxes of every 16th node
   tonemap.npz            Render::saveFile: a buffer of hard values (zero, one, beyond both, denormals,
                          NaN, infinities, both sides of every 8-bit step) and the PPM the reference wrote
   ref_render_NxN_4096spp.npy        Render::renderPathTracing float buffer, N = 128 and 256
@@ -75,6 +79,14 @@ def photon_maps(R):
     print("photon maps:", {k: v.shape for k, v in out.items()})
 
 
+def tree_tied_keys(R):
+    spec = _rays.heightfield_spec(72)
+    spec["objects"] = spec["objects"][-1:]  # the mesh alone: the flattened tree is the mesh's own
+    lo, hi, child, prim = R.build_scene(spec).flatten()
+    np.savez_compressed(os.path.join(HERE, "tree_tied_keys.npz"), cells=72, prim=prim, child=child,
+                        bmin16=lo[::16], bmax16=hi[::16])
+
+
 def tonemap(R):
     """Render::saveFile (src/Render.cpp:3-21) of the reference on values chosen to be hard for
     `(unsigned char)(255 * pow(clamp(0, 1, v), 0.6f))`: around every step of the 8-bit output."""
@@ -130,6 +142,10 @@ def main():
     if "--only-tonemap" in sys.argv:
         tonemap(R)
         return
+    if "--only-tree" in sys.argv:
+        tree_tied_keys(R)
+        return
+    tree_tied_keys(R)
     if "--only-photons" in sys.argv:
         photon_maps(R)
         return

@@ -51,6 +51,42 @@ def test_bvh_golden(osc):
     assert np.array_equal(_rays.bits(areas), _rays.bits(g["areas"]))
 
 
+def _check_tree_against_reference(flat):
+    """flat = (bmin, bmax, child, prim) of the mesh-only 72 x 72 grid scene against what the
+    reference's BVH::selfBuildBVH built (tests/golden/tree_tied_keys.npz)."""
+    g = _load("tree_tied_keys.npz")
+    lo, hi, child, prim = flat
+    assert np.array_equal(prim, g["prim"]) and np.array_equal(child, g["child"])
+    assert np.array_equal(_rays.bits(lo[::16]), _rays.bits(g["bmin16"]))
+    assert np.array_equal(_rays.bits(hi[::16]), _rays.bits(g["bmax16"]))
+
+
+def _tied_grid_spec():
+    spec = _rays.heightfield_spec(72)
+    spec["objects"] = spec["objects"][-1:]
+    return spec
+
+
+def test_tree_with_tied_keys_golden_checker():
+    """Whole rows of box centres tie: the tree depends on the order std::sort leaves equal keys in."""
+    _check_tree_against_reference(Oracle().build_scene(_tied_grid_spec()).flatten())
+
+
+def test_tree_with_tied_keys_golden_host_builder(monkeypatch):
+    import raytracingrenderer_amd as rt
+    monkeypatch.setenv("RTR_TREE_BUILDER", "host")
+    _check_tree_against_reference(rt.HostScene.from_spec(_tied_grid_spec()).flatten())
+
+
+@pytest.mark.gpu
+def test_tree_with_tied_keys_golden_device_builder(monkeypatch):
+    """rtr_build_bvh directly against the reference's tree: 10 368 triangles take the kernels over
+    the whole array (ranges above 2048 objects) and the subtrees in LDS."""
+    import raytracingrenderer_amd as rt
+    monkeypatch.setenv("RTR_TREE_BUILDER", "device")
+    _check_tree_against_reference(rt.HostScene.from_spec(_tied_grid_spec()).flatten())
+
+
 def _check_hits(got, g):
     p, t, pos, nrm = got
     assert np.array_equal(p, g["prim"])
