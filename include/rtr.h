@@ -216,6 +216,8 @@ int rtr_self_test(int device, uint64_t *mismatches);
  * order (median-of-three Hoare partitions by parallel ranks, heap sort where the depth budget
  * runs out, the final insertion sort as a stable ranking).  Box planes carry the reference's bits,
  * the sign of a zero plane included.
+ * device: where to build; negative = the calling thread's current HIP device (a process that has
+ * chosen its GPU, like one rank of a multi-process run, builds there without naming it).
  * obj_bmin / obj_bmax: the objects' boxes (Object::getBound), [0]=x [1]=y [2]=z, host memory; all
  * planes must be finite.  Outputs (host memory, 2 * n_objects - 1 nodes, numbered depth first,
  * left child first -- node 0 is the root, the left child of node i is node i + 1, which is the

@@ -11,7 +11,8 @@ import numpy as np
 from .scenes import default_scene_spec  # noqa: F401  (part of this module's interface)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(_HERE, "librtr_hip.so")
+# RTR_HIP_SO: another build of the library (development: variants built with experiment switches)
+HIP_SO = os.environ.get("RTR_HIP_SO") or os.path.join(_HERE, "librtr_hip.so")
 HOST_SO = os.path.join(_HERE, "librtr_host.so")
 
 DIFFUSE, SPECULAR, MICROFACET = 0, 1, 2

@@ -767,7 +767,8 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
     fprintf(stderr, "rtr_build_bvh %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  if (hipSetDevice(device) != hipSuccess) return rtr::fail_msg(RTR_ERR_DEVICE, "rtr_build_bvh: no such device");
+  if (device >= 0 && hipSetDevice(device) != hipSuccess)
+    return rtr::fail_msg(RTR_ERR_DEVICE, "rtr_build_bvh: no such device");
   TB_TRY(hipMalloc((void **)&d_box, sizeof(float) * 6 * n));
   TB_TRY(hipMalloc((void **)&d_key, sizeof(float) * n));
   TB_TRY(hipMalloc((void **)&d_idx, sizeof(uint32_t) * n));

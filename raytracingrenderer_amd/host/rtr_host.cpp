@@ -182,7 +182,7 @@ BVHNode *BVH::build(std::vector<Object *> &objs) {
 
 BVH::Builder BVH::builder = BVH::Auto;
 size_t BVH::deviceMin = 1 << 13;
-int BVH::buildDevice = 0;
+int BVH::buildDevice = -1;  // the calling thread's current device
 
 void BVH::clear() {
   if (arena) free(arena);  // BVHNode has no destructor to run
@@ -261,7 +261,7 @@ void BVH::buildBVH(std::vector<Object *> &objs) {
   bool on_device = how == Device && !objs.empty();
   if (how == Auto && objs.size() >= deviceMin) {
     int devices = 0;
-    on_device = rtr_device_count(&devices) == RTR_OK && devices > buildDevice;
+    on_device = rtr_device_count(&devices) == RTR_OK && devices > (buildDevice < 0 ? 0 : buildDevice);
     if (on_device)  // the kernels take finite boxes only; anything else is the host's
       for (Object *o : objs) {
         const Bound3 b = o->getBound();

@@ -144,7 +144,7 @@ class BVH {
   enum Builder { Auto, Host, Device };
   static Builder builder;
   static size_t deviceMin;
-  static int buildDevice;
+  static int buildDevice;  // negative: the calling thread's current HIP device
   BVH() {}
   ~BVH() { clear(); }
   BVH(const BVH &) = delete;
