@@ -73,6 +73,15 @@ def test_random_triangles(rt, n):
     _assert_same_tree(rt, _mesh_only(v, i))
 
 
+@pytest.mark.parametrize("scale", [1e-42, 3e-39, 1e30])
+def test_tiny_and_huge_coordinates(rt, scale):
+    """Box planes and centres that are subnormal numbers (the kernels must not flush them) or near
+    the top of the range (min * 0.5 + max * 0.5 does not overflow where (min + max) / 2 would)."""
+    rng = np.random.default_rng(5)
+    v = (rng.uniform(-300, 300, (9000, 3, 3)) * scale).astype(f32)
+    _assert_same_tree(rt, _mesh_only(v.reshape(-1, 3), np.arange(27000, dtype=np.uint32)))
+
+
 @pytest.mark.parametrize("cells", [3, 30, 150, 400])
 def test_grid_meshes_with_tied_keys(rt, cells):
     """Height fields over a regular grid: whole rows of triangles share a box centre on two axes."""
