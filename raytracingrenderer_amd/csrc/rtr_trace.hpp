@@ -1421,7 +1421,12 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
     if (pair != 0) {
       const float4 q0 = lds.pair_second[3 * pair - 3], q1 = lds.pair_second[3 * pair - 2],
                    q2 = lds.pair_second[3 * pair - 1];
-      const V3x2 m1 = V3x2{negate_nonzero(s1.x), negate_nonzero(s1.y), negate_nonzero(s1.z)};
+      // s1' enters the second test through dot(s1', s) alone.  Its non-zero components are the first
+      // triangle's negated; a zero component's sign (the same zero as the first triangle's, where
+      // plain negation gives the other one) can only show when every product of that sum is a
+      // zero, and then b1 is a zero of either sign, below the test's epsilon both ways: the
+      // triangle is not hit, and neither the comparison nor the minimum nor t_sum sees the sign.
+      const V3x2 m1 = V3x2{-s1.x, -s1.y, -s1.z};
       finish(o - xyz(q0), xyz(q1), xyz(q2), m1, inv, thr, k + 1);
     }
   };
