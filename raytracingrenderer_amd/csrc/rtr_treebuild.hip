@@ -752,6 +752,7 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
   uint32_t *d_idx = nullptr, *d_pl = nullptr, *d_pr = nullptr, *d_root = nullptr, *d_flags = nullptr;
   int32_t *d_links = nullptr;
   unsigned long long *d_planes = nullptr;
+  char *d_all = nullptr;
   SortQueues q;
   memset(&q, 0, sizeof(q));
   NodeOut out;
@@ -769,13 +770,42 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
   };
   if (device >= 0 && hipSetDevice(device) != hipSuccess)
     return rtr::fail_msg(RTR_ERR_DEVICE, "rtr_build_bvh: no such device");
-  TB_TRY(hipMalloc((void **)&d_box, sizeof(float) * 6 * n));
-  TB_TRY(hipMalloc((void **)&d_key, sizeof(float) * n));
-  TB_TRY(hipMalloc((void **)&d_idx, sizeof(uint32_t) * n));
-  TB_TRY(hipMalloc((void **)&d_root, sizeof(uint32_t) * n));
-  TB_TRY(hipMalloc((void **)&d_nodes, sizeof(float) * 6 * n_nodes));
-  TB_TRY(hipMalloc((void **)&d_links, sizeof(int32_t) * 3 * n_nodes));
-  TB_TRY(hipMalloc((void **)&d_flags, sizeof(uint32_t)));
+  // one allocation for everything (a dozen separate ones cost more than the kernels of a small tree)
+  {
+    const size_t big_cap = (size_t)n / kT + 2, tile_cap = (size_t)n / kTile + big_cap;
+    size_t total = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = total;
+      total += (bytes + 255) & ~(size_t)255;
+      return at;
+    };
+    const size_t o_box = take(sizeof(float) * 6 * n), o_key = take(sizeof(float) * n);
+    const size_t o_idx = take(sizeof(uint32_t) * n), o_root = take(sizeof(uint32_t) * n);
+    const size_t o_nodes = take(sizeof(float) * 6 * n_nodes), o_links = take(sizeof(int32_t) * 3 * n_nodes);
+    const size_t o_flags = take(sizeof(uint32_t));
+    size_t o_pl = 0, o_pr = 0, o_planes = 0, o_big[2] = {0, 0}, o_bigc = 0, o_small = 0, o_smallc = 0, o_tiles = 0;
+    if (Ls > 0) {
+      o_pl = take(sizeof(uint32_t) * n), o_pr = take(sizeof(uint32_t) * n);
+      o_planes = take(sizeof(unsigned long long) * 6 * ((size_t)1 << (Ls - 1)));
+      o_big[0] = take(sizeof(BigRange) * big_cap), o_big[1] = take(sizeof(BigRange) * big_cap);
+      o_bigc = take(sizeof(unsigned long long) * 2);
+      o_small = take(sizeof(QsRange) * list_cap), o_smallc = take(sizeof(int));
+      o_tiles = take(sizeof(uint32_t) * tile_cap);
+    }
+    TB_TRY(hipMalloc((void **)&d_all, total));
+    d_box = (float *)(d_all + o_box), d_key = (float *)(d_all + o_key);
+    d_idx = (uint32_t *)(d_all + o_idx), d_root = (uint32_t *)(d_all + o_root);
+    d_nodes = (float *)(d_all + o_nodes), d_links = (int32_t *)(d_all + o_links);
+    d_flags = (uint32_t *)(d_all + o_flags);
+    if (Ls > 0) {
+      d_pl = (uint32_t *)(d_all + o_pl), d_pr = (uint32_t *)(d_all + o_pr);
+      d_planes = (unsigned long long *)(d_all + o_planes);
+      q.big[0] = (BigRange *)(d_all + o_big[0]), q.big[1] = (BigRange *)(d_all + o_big[1]);
+      q.big_count = (unsigned long long *)(d_all + o_bigc);
+      q.small = (QsRange *)(d_all + o_small), q.small_count = (int *)(d_all + o_smallc);
+      q.tile_counts = (uint32_t *)(d_all + o_tiles);
+    }
+  }
   TB_TRY(hipMemset(d_flags, 0, sizeof(uint32_t)));
   for (int a = 0; a < 3; a++) {
     TB_TRY(hipMemcpy(d_box + (size_t)a * n, obj_bmin[a], sizeof(float) * n, hipMemcpyHostToDevice));
@@ -793,17 +823,6 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
       rc = rtr::fail_msg(RTR_ERR_INVALID, "rtr_build_bvh: a box plane is infinite or not a number");
       goto done;
     }
-  }
-  if (Ls > 0) {
-    TB_TRY(hipMalloc((void **)&d_pl, sizeof(uint32_t) * n));
-    TB_TRY(hipMalloc((void **)&d_pr, sizeof(uint32_t) * n));
-    TB_TRY(hipMalloc((void **)&d_planes, sizeof(unsigned long long) * 6 * ((size_t)1 << (Ls - 1))));
-    const size_t big_cap = (size_t)n / kT + 2, tile_cap = (size_t)n / kTile + big_cap;
-    for (int i = 0; i < 2; i++) TB_TRY(hipMalloc((void **)&q.big[i], sizeof(BigRange) * big_cap));
-    TB_TRY(hipMalloc((void **)&q.big_count, sizeof(unsigned long long) * 2));
-    TB_TRY(hipMalloc((void **)&q.small, sizeof(QsRange) * list_cap));
-    TB_TRY(hipMalloc((void **)&q.small_count, sizeof(int)));
-    TB_TRY(hipMalloc((void **)&q.tile_counts, sizeof(uint32_t) * tile_cap));
   }
   for (int L = 0; L < Ls; L++) {
     const int ranges = 1 << L;
@@ -850,10 +869,7 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
   if (root_order) TB_TRY(hipMemcpy(root_order, d_root, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
   mark("download");
 done:
-  (void)hipFree(d_box), (void)hipFree(d_key), (void)hipFree(d_idx), (void)hipFree(d_root);
-  (void)hipFree(d_nodes), (void)hipFree(d_links), (void)hipFree(d_flags), (void)hipFree(d_pl);
-  (void)hipFree(d_pr), (void)hipFree(d_planes), (void)hipFree(q.big[0]), (void)hipFree(q.big[1]);
-  (void)hipFree(q.big_count), (void)hipFree(q.small), (void)hipFree(q.small_count), (void)hipFree(q.tile_counts);
+  (void)hipFree(d_all);
   mark("free");
   return rc;
 }

@@ -4,6 +4,7 @@
 #include "rtr_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -193,7 +194,9 @@ void BVH::clear() {
 
 // BVH::selfBuildBVH by the kernels behind rtr_build_bvh: the objects' boxes go over, node arrays
 // come back (numbered level by level, node 0 the root) and become BVHNodes in one block.
-BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
+// Returns null, having done nothing, when `finite_only` is set and some box plane is infinite or
+// not a number (the kernels take finite boxes only; such a tree is the host builder's).
+BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs, bool finite_only) {
   const size_t n = objs.size(), nn = 2 * n - 1;
   const bool times = getenv("RTR_TREE_TIMES") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -205,13 +208,18 @@ BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs) {
   };
   BulkVector<float> ob[6], nb[6];
   for (int a = 0; a < 6; a++) ob[a].resize(n), nb[a].resize(nn);
+  std::atomic<bool> finite{true};
   parallel_ranges(n, [&](size_t from, size_t to) {
+    bool ok = true;
     for (size_t k = from; k < to; k++) {
       const Bound3 b = objs[k]->getBound();
       ob[0][k] = b.min.x, ob[1][k] = b.min.y, ob[2][k] = b.min.z;
       ob[3][k] = b.max.x, ob[4][k] = b.max.y, ob[5][k] = b.max.z;
+      for (int a = 0; a < 6; a++) ok = ok && std::isfinite(ob[a][k]);
     }
+    if (!ok) finite = false;
   });
+  if (finite_only && !finite) return nullptr;
   BulkVector<int32_t> left(nn), right(nn), object(nn), order(n);
   const float *omin[3] = {ob[0].data(), ob[1].data(), ob[2].data()};
   const float *omax[3] = {ob[3].data(), ob[4].data(), ob[5].data()};
@@ -262,14 +270,9 @@ void BVH::buildBVH(std::vector<Object *> &objs) {
   if (how == Auto && objs.size() >= deviceMin) {
     int devices = 0;
     on_device = rtr_device_count(&devices) == RTR_OK && devices > (buildDevice < 0 ? 0 : buildDevice);
-    if (on_device)  // the kernels take finite boxes only; anything else is the host's
-      for (Object *o : objs) {
-        const Bound3 b = o->getBound();
-        const float v[6] = {b.min.x, b.min.y, b.min.z, b.max.x, b.max.y, b.max.z};
-        for (float f : v) on_device = on_device && std::isfinite(f);
-      }
   }
-  root = on_device ? buildOnDevice(objs) : build(objs);
+  if (on_device) root = buildOnDevice(objs, how == Auto);  // forced: a bad box is the call's error
+  if (!root) root = build(objs);
 }
 
 // ---------------- TrangleMesh (include/Trangle.h:60-95) ----------------

@@ -133,7 +133,7 @@ class BVH {
   BVHNode *root = nullptr;
   BVHNode *arena = nullptr;  // one block holding the nodes of a tree that came from the device as arrays
   static BVHNode *build(std::vector<Object *> &objs);
-  BVHNode *buildOnDevice(std::vector<Object *> &objs);
+  BVHNode *buildOnDevice(std::vector<Object *> &objs, bool finite_only);
   static void destroy(BVHNode *n);
   void clear();
 
