@@ -219,7 +219,9 @@ int rtr_self_test(int device, uint64_t *mismatches);
  * device: where to build; negative = the calling thread's current HIP device (a process that has
  * chosen its GPU, like one rank of a multi-process run, builds there without naming it).
  * obj_bmin / obj_bmax: the objects' boxes (Object::getBound), [0]=x [1]=y [2]=z, host memory; all
- * planes must be finite.  Outputs (host memory, 2 * n_objects - 1 nodes, numbered depth first,
+ * planes must be finite (RTR_ERR_INVALID otherwise).  RTR_ERR_UNSUPPORTED: the reference's sort
+ * falls back to heap-sorting a range of more than 2^17 objects for these boxes (key orders built
+ * to defeat its median of three), a sequential job that is left to the host.  Outputs (host memory, 2 * n_objects - 1 nodes, numbered depth first,
  * left child first -- node 0 is the root, the left child of node i is node i + 1, which is the
  * order BVH::intersect, src/BVH.cpp:66-80, visits them in): the nodes' boxes, children (-1 for a leaf) and the leaf's object
  * index (-1 for an inner node) -- the node arrays of rtr_scene_desc once object indices are

@@ -239,7 +239,12 @@ struct SortQueues {
   QsRange *small;                   // ranges of at most kT objects, finished in LDS
   int *small_count;
   uint32_t *tile_counts;            // per tile: left | right << 16 candidates
+  uint32_t *flags;                  // bit 0: a box plane is not finite; bit 1: a heap sort too long for one lane
 };
+// A heap sort is one lane's work, a dependent chain of memory accesses: ranges beyond this many
+// objects (only key sequences built to defeat the median of three get there) are refused instead
+// of holding the device for seconds.
+constexpr int kHeapSortMax = 1 << 17;
 
 __device__ inline void push_small(const SortQueues &q, int f, int l, int depth) {
   q.small[atomicAdd(q.small_count, 1)] = QsRange{f, l, depth, 0};
@@ -248,7 +253,11 @@ __device__ inline void push_small(const SortQueues &q, int f, int l, int depth) 
 // rest between rounds), so that every tile of the round finds the pivot at f.  A range whose depth
 // budget is spent is heap-sorted here, by this one lane, and not queued.
 __device__ inline void push_big(const SortQueues &q, int to, GlobalRecords rec, int f, int l, int depth) {
-  if (depth == 0) return rtr::heap_sort(rec, f, l);
+  if (depth == 0) {
+    if (l - f > kHeapSortMax) atomicOr(q.flags, 2u);
+    else rtr::heap_sort(rec, f, l);
+    return;
+  }
   rtr::median_to_first(rec, f, f + 1, f + (l - f) / 2, l - 1);
   const int tiles = (l - f - 1 + kTile - 1) / kTile;
   const unsigned long long old = atomicAdd(&q.big_count[to], (1ull << 32) | (unsigned long long)tiles);
@@ -804,6 +813,7 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
       q.big_count = (unsigned long long *)(d_all + o_bigc);
       q.small = (QsRange *)(d_all + o_small), q.small_count = (int *)(d_all + o_smallc);
       q.tile_counts = (uint32_t *)(d_all + o_tiles);
+      q.flags = d_flags;
     }
   }
   TB_TRY(hipMemset(d_flags, 0, sizeof(uint32_t)));
@@ -857,7 +867,16 @@ extern "C" int rtr_build_bvh(int device, int32_t n_objects, const float *const o
   mark("upper levels");
   k_tb_subtree<<<1 << Ls, kWG>>>(n, Ls, d_idx, d_box, out, d_root);
   TB_TRY(hipGetLastError());
-  TB_TRY(hipDeviceSynchronize());
+  {
+    uint32_t flags = 0;
+    TB_TRY(hipMemcpy(&flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags & 2u) {
+      rc = rtr::fail_msg(RTR_ERR_UNSUPPORTED,
+                         "rtr_build_bvh: the reference's sort heap-sorts a range of more than 2^17 objects "
+                         "for these boxes, which is not done on the device");
+      goto done;
+    }
+  }
   mark("subtrees");
   for (int a = 0; a < 3; a++) {
     TB_TRY(hipMemcpy(node_bmin[a], out.bmin[a], sizeof(float) * n_nodes, hipMemcpyDeviceToHost));

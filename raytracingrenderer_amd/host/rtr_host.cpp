@@ -194,8 +194,8 @@ void BVH::clear() {
 
 // BVH::selfBuildBVH by the kernels behind rtr_build_bvh: the objects' boxes go over, node arrays
 // come back (numbered level by level, node 0 the root) and become BVHNodes in one block.
-// Returns null, having done nothing, when `finite_only` is set and some box plane is infinite or
-// not a number (the kernels take finite boxes only; such a tree is the host builder's).
+// Returns null, having changed nothing, when `finite_only` is set and the kernels decline the job:
+// some box plane is infinite or not a number, or the sort needs a heap sort too long for one lane.
 BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs, bool finite_only) {
   const size_t n = objs.size(), nn = 2 * n - 1;
   const bool times = getenv("RTR_TREE_TIMES") != nullptr;
@@ -234,9 +234,10 @@ BVHNode *BVH::buildOnDevice(std::vector<Object *> &objs, bool finite_only) {
     }
   });
   mark("boxes");
-  if (rtr_build_bvh(buildDevice, (int32_t)n, omin, omax, nmin, nmax, left.data(), right.data(),
-                    object.data(), order.data()) != RTR_OK)
-    throw std::runtime_error(std::string("rtr_build_bvh: ") + rtr_last_error());
+  const int rc = rtr_build_bvh(buildDevice, (int32_t)n, omin, omax, nmin, nmax, left.data(), right.data(),
+                               object.data(), order.data());
+  if (rc == RTR_ERR_UNSUPPORTED && finite_only) return nullptr;  // a sort the kernels leave to the host
+  if (rc != RTR_OK) throw std::runtime_error(std::string("rtr_build_bvh: ") + rtr_last_error());
   mark("rtr_build_bvh");
   // raw storage, first touched by the threads that fill it
   arena = static_cast<BVHNode *>(malloc(nn * sizeof(BVHNode)));

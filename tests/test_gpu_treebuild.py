@@ -153,6 +153,27 @@ def test_root_order_and_raw_arrays(rt):
     assert under(left[0]) == sorted(order[:n // 2])
 
 
+def test_long_heap_sorts_are_left_to_the_host(rt):
+    """An organ pipe of 1.2 M keys drives the root's sort into heap-sorting a range of more than
+    2^17 keys (157 000, counted with libstdc++'s own partition): one lane's work for seconds, which
+    rtr_build_bvh declines; the host mirror then builds that tree with std::sort."""
+    n = 1200000
+    i = np.arange(n)
+    keys = (np.minimum(i, n - i) // 2).astype(f32)
+    lo = np.zeros((n, 3), f32)
+    lo[:, 0] = keys
+    with pytest.raises(rt.RtrError, match="heap-sorts"):
+        rt.build_bvh(lo, lo)
+    v, idx = _points_on_a_line(keys)
+    spec = _mesh_only(v, idx)
+    host = _flatten_with(rt, spec, "host")
+    s = rt.HostScene.from_spec(spec)  # builder chosen by size: the device declines, the host builds
+    auto = s.flatten()
+    s.close()
+    for a, b in zip(host, auto):
+        assert np.array_equal(_rays.bits(a), _rays.bits(b))
+
+
 def test_infinite_boxes_are_refused(rt):
     lo = np.zeros((10, 3), f32)
     hi = np.ones((10, 3), f32)
