@@ -204,3 +204,21 @@ def test_fused_kernel_spill_gate():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "k_render_fusedILb1E" in r.stdout
+
+
+def test_parallel_form_of_std_sort_matches_std_sort(tmp_path):
+    """The tree builder's kernels rest on a reformulation of libstdc++'s std::sort (Hoare partitions by
+    ranks, all ranges of a round at once, heap sort and median of three move for move as in
+    raytracingrenderer_amd/csrc/rtr_heapsort.hpp -- the header the kernels include --, the final
+    insertion sort as a stable sort).  tools/introsort_model.cpp runs that formulation on the CPU
+    against std::sort itself on key sets with ties."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "introsort_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools", "introsort_model.cpp")])
+    out = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok: 600 cases"), out.stdout + out.stderr
+    heaps = int(out.stdout.split(",")[1].split()[0])
+    assert heaps > 0  # some of the cases exhaust the depth budget and end in heap sorts

@@ -3,7 +3,7 @@
 // std::sort itself on records whose keys tie.  Every step below is written as "what each element
 // can compute from scans", executed sequentially here.
 //
-//   g++ -O2 -std=c++17 -o /tmp/introsort_model tools/introsort_model.cpp && /tmp/introsort_model
+//   g++ -O2 -std=c++17 -o /tmp/introsort_model tools/introsort_model.cpp && /tmp/introsort_model [trials]
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -78,10 +78,11 @@ static void model_sort(std::vector<Rec> &a, int lo, int hi) {
   std::stable_sort(a.begin() + lo, a.begin() + hi, less);
 }
 
-int main() {
+int main(int argc, char **argv) {
   std::mt19937 rng(7);
   long cases = 0;
-  for (int trial = 0; trial < 4000; trial++) {
+  const int trials = argc > 1 ? atoi(argv[1]) : 4000;
+  for (int trial = 0; trial < trials; trial++) {
     int n = 1 + rng() % (trial % 50 == 0 ? 200000 : 3000);
     int distinct = 1 + rng() % (1 + rng() % (2 * n));
     std::vector<Rec> a(n);
