@@ -259,7 +259,8 @@ int rtr_scene_read_tree(rtr_scene *scene, int32_t *n_nodes, int32_t *n_leaves, f
  * the record table its pass over the leaves reads, copied back (for checks and tools): the
  * leaf records of rtr_scene_read_tree in the same order, except that of two neighbouring
  * triangle leaves that split a parallelogram (p0 p1 p2 / p3 p2 p1: e1' = -e1, e2' = -e2
- * exactly, equal normals -- every wall of the scene of src/main.cpp:26-39) only the first
+ * exactly, equal normals, no vertex coordinate of the second one written as -0 -- every wall
+ * of the scene of src/main.cpp:26-39) only the first
  * has a record, whose 13th word holds 1 + the pair's number; seconds12 holds the second
  * triangles' {p0, -}{e1, -}{e2, -} by pair.  The kernel takes the direction-dependent terms
  * of the second triangle's test (src/Trangle.cpp:10-12) over from the first.  No counterpart

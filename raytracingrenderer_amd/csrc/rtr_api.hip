@@ -333,7 +333,7 @@ int build_scene_arrays(rtr_scene *s, const rtr_scene_desc *d, bool info_fits, Bu
     if (L <= (size_t)kLdsLeaves) {
       HIP_TRY(s->items.reserve(4 * (L + 1)));
       HIP_TRY(s->pair_second.reserve(3 * (L / 2 + 1)));
-      hipLaunchKernelGGL(k_build_items, dim3(1), dim3(64), 0, st, s->leaves.ptr, (int)L, s->items.ptr,
+      hipLaunchKernelGGL(k_build_items, dim3(1), dim3(64), 0, st, s->leaves.ptr, (int)L, out.tris, s->items.ptr,
                          s->pair_second.ptr, dflags.ptr);
     }
     HIP_TRY(hipGetLastError());

@@ -272,8 +272,19 @@ __device__ inline bool mirrored_component(float a, float b) {
   const float m = fabsf(a);
   return m >= 8.673617379884035e-19f && m <= 1152921504606846976.0f;  // false for -0, infinity, NaN
 }
-__global__ void k_build_items(float4 *leaves, int n_leaves, float4 *items, float4 *pair_second,
-                              BuildFlags *flags) {
+// The second triangle of a pair takes its s1 from the first one by plain negation, which gives a
+// zero component the other sign than its own evaluation would.  That sign reaches nothing but b1
+// when b1 is a zero, and a zero b1 of either sign reaches nothing but the hit's position
+// p0 w + p1 b1 + p2 b2 (src/Trangle.cpp:23), where p1 * (+-0) is absorbed by a non-zero sum, and by
+// a sum of zeros as well when no vertex coordinate is -0: w + b2 = 1 then, so one of the two other
+// terms has a positive weight, and is non-zero or +0, which makes the sum +0 whatever the other
+// zeros' signs.  Hence: no pair when a coordinate of the second triangle is -0.
+__device__ inline bool has_negative_zero(float4 v) {
+  return __float_as_uint(v.x) == 0x80000000u || __float_as_uint(v.y) == 0x80000000u ||
+         __float_as_uint(v.z) == 0x80000000u;
+}
+__global__ void k_build_items(float4 *leaves, int n_leaves, const float4 *tris, float4 *items,
+                              float4 *pair_second, BuildFlags *flags) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int32_t j = 0;
   for (int k = 0; k < n_leaves; k++)
@@ -288,7 +299,9 @@ __global__ void k_build_items(float4 *leaves, int n_leaves, float4 *items, float
                        mirrored_component(a[1].z, b[1].z) && mirrored_component(a[2].x, b[2].x) &&
                        mirrored_component(a[2].y, b[2].y) && mirrored_component(a[2].z, b[2].z);
     const bool normals = a[0].w == b[0].w && a[1].w == b[1].w && a[2].w == b[2].w;  // false for NaN
-    if (edges && normals) {
+    const float4 *vb = tris + 3 * (__float_as_int(b[3].w) & 0x3fffffff);  // the second triangle's p0, p1, p2
+    const bool zeros = !has_negative_zero(vb[0]) && !has_negative_zero(vb[1]) && !has_negative_zero(vb[2]);
+    if (edges && normals && zeros) {
       pair_second[3 * n_pairs] = b[0];
       pair_second[3 * n_pairs + 1] = b[1];
       pair_second[3 * n_pairs + 2] = b[2];

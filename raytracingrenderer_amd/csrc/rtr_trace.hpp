@@ -1424,8 +1424,9 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
       // s1' enters the second test through dot(s1', s) alone.  Its non-zero components are the first
       // triangle's negated; a zero component's sign (the same zero as the first triangle's, where
       // plain negation gives the other one) can only show when every product of that sum is a
-      // zero, and then b1 is a zero of either sign, below the test's epsilon both ways: the
-      // triangle is not hit, and neither the comparison nor the minimum nor t_sum sees the sign.
+      // zero: then b1 is a zero of one sign or the other.  No comparison, minimum or t_sum sees
+      // that sign, and the hit's position does not either for the pairs the upload forms
+      // (k_build_items: no vertex coordinate of the second triangle is -0).
       const V3x2 m1 = V3x2{-s1.x, -s1.y, -s1.z};
       finish(o - xyz(q0), xyz(q1), xyz(q2), m1, inv, thr, k + 1);
     }

@@ -827,11 +827,46 @@ def test_device_tree_layout(rt, which):
         if len(seconds):
             assert np.array_equal(seconds[:, keep].view(np.uint32),
                                   np.array(want_seconds, f32)[:, keep].view(np.uint32))
+        # (a third condition -- no vertex coordinate of the second triangle is -0 -- is vacuous for
+        # these scenes and has a test of its own: test_walls_with_negative_zero_coordinates)
+        for ob in spec["objects"]:
+            if ob[0] == "mesh":
+                assert not (np.signbit(np.asarray(ob[2], f32)) & (np.asarray(ob[2], f32) == 0)).any()
         if which == "default":  # every wall of the reference's scene is a parallelogram split in two
             assert len(seconds) == (~sph).sum() // 2 > 0
     else:
         records, seconds = sg.read_pairs()
         assert len(records) == 0 and len(seconds) == 0
+
+
+def test_walls_with_negative_zero_coordinates(rt):
+    """The default scene with every zero vertex coordinate written as -0: a wall's two triangles are
+    then tested each on its own (the shared-direction short cut gives a zero of the other sign where
+    the reference's arithmetic has one, which a -0 coordinate could carry into a hit's position), and
+    images stay equal to the checker's bit for bit."""
+    spec = default_scene_spec()
+    objs = []
+    for ob in spec["objects"]:
+        if ob[0] == "mesh":
+            v = np.asarray(ob[2], f32).copy()
+            v[v == 0] = -0.0
+            ob = (ob[0], ob[1], v, ob[3])
+        objs.append(ob)
+    spec["objects"] = objs
+    O = Oracle()
+    so = O.build_scene(spec)
+    O.set_math(so, portable=True)
+    sg = rt.HostScene.from_spec(spec)
+    records, seconds = sg.read_pairs()
+    walls_with_zero = sum(1 for ob in objs if ob[0] == "mesh" and (ob[2] == 0).any())
+    assert walls_with_zero > 0 and len(seconds) < 5  # walls that touch a zero plane form no pair
+    org, d = _rays.default_batch(O, so, n_interior=20000, prim_step=16)
+    _assert_hits_equal(sg.intersect(org, d), so.intersect(org, d))
+    img, stats = O.render(so, 64, 64, 16, seed=4, chunk_spp=4)
+    for how in (dict(), dict(mode=1)):
+        rgb, st = sg.render(64, 64, 16, seed=4, chunk_spp=4, **how)
+        _assert_images_equal(rgb, img)
+        assert st.rays == stats[1] and st.vertices == stats[3]
 
 
 def test_scene_create_rejects_malformed_trees(rt):
