@@ -1200,15 +1200,6 @@ struct BestHit {
   }
 };
 
-// x for a zero of either sign, -x otherwise
-RTR_DEV f32x2 negate_nonzero(f32x2 v) {
-  return f32x2{v.x == 0.0f ? v.x : -v.x, v.y == 0.0f ? v.y : -v.y};
-}
-RTR_DEV bool mirror_dir_ok(V3 d) {
-  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-  return fminf(fminf(ax, ay), az) >= kFastLo && fmaxf(fmaxf(ax, ay), az) <= 2.0f;
-}
-
 // The hardware's minimum / maximum of three (a NaN operand is passed over, like fminf does).
 // Written out because the compiler's fminf first re-canonicalises operands that come out of
 // packed arithmetic (one more instruction each at the rate of a compare).
@@ -1340,9 +1331,9 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   // second one out of the record table, marks the first and keeps the second's own p0, e1, e2
   // by pair.  Of the second triangle's test,
   //   s1' = cross(dn, e2'): every product changes sign, so a non-zero component is the first
-  //        triangle's negated and a zero component (both products zero, or equal) is the same
-  //        zero -- provided no product underflows: direction components of magnitude in
-  //        [2^-20, 2];
+  //        triangle's negated -- provided no product underflows: direction components of
+  //        magnitude in [2^-20, 2] -- and a zero component (both products zero, or equal) is a
+  //        zero, whose sign nothing downstream can see (below, where the second test is made);
   //   se' = dot(s1', e1'): the same non-zero products in the same order (zero products may
   //        differ in sign, which a non-zero sum does not see): the same bits unless se is zero;
   //   1 / se' follows, and so does the facing test (normals equal as numbers: `< 0` of the
