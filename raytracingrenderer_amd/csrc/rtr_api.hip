@@ -303,7 +303,7 @@ int build_scene_arrays(rtr_scene *s, const rtr_scene_desc *d, bool info_fits, Bu
   auto grid = [](size_t n) { return dim3((unsigned)((n + kBuildBlock - 1) / kBuildBlock)); };
   if (P) hipLaunchKernelGGL(k_build_prims, grid(P), dim3(kBuildBlock), 0, st, in, out, dflags.ptr);
   if (T || S)
-    hipLaunchKernelGGL(k_build_geometry, grid(std::max(T, S)), dim3(kBuildBlock), 0, st, in, out);
+    hipLaunchKernelGGL(k_build_geometry, grid(std::max(T, S)), dim3(kBuildBlock), 0, st, in, out, dflags.ptr);
   if (N) {
     hipLaunchKernelGGL(k_build_links, grid(N), dim3(kBuildBlock), 0, st, in, tmp, dflags.ptr);
     hipLaunchKernelGGL(k_build_count, grid(N), dim3(kBuildBlock), 0, st, in, tmp, dflags.ptr);
@@ -541,9 +541,16 @@ int enqueue_front(rtr_scene *s, const RenderPlan &pl, const RenderBuffers &b, hi
   return RTR_OK;
 }
 
+// The flavour of the fused kernel that takes the short cuts of a scene whose arithmetic cannot
+// overflow: planes in the division-free test's range, nested boxes, primitives within 2^20.
+bool bounded_scene(const rtr_scene *s) {
+  return s->lds_geometry && s->ds.fast_planes != 0 && s->ds.nested_boxes != 0 && s->ds.near_prims != 0;
+}
+
 int fused_grid(rtr_scene *s) {
-  if (s->lds_geometry) return resident_grid(s, k_render_fused<true>, s->fused_grid);
-  return resident_grid(s, k_render_fused<false>, s->fused_grid);
+  if (bounded_scene(s)) return resident_grid(s, k_render_fused<true, true>, s->fused_grid);
+  if (s->lds_geometry) return resident_grid(s, k_render_fused<true, false>, s->fused_grid);
+  return resident_grid(s, k_render_fused<false, false>, s->fused_grid);
 }
 
 // The whole sampling loop as one launch.  The kernel reads the number of pixels that need
@@ -557,12 +564,16 @@ int enqueue_fused(rtr_scene *s, const RenderPlan &pl, const RenderBuffers &b, hi
   unsigned grid = (unsigned)s->fused_grid;
   if ((uint64_t)grid * kBlock > pl.units) grid = (unsigned)((pl.units + kBlock - 1) / kBlock);
   HIP_TRY(ev.run(st, kSpanFused, [&] {
-    if (s->lds_geometry)
-      hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+    if (bounded_scene(s))
+      hipLaunchKernelGGL((k_render_fused<true, true>), dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+                         s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, b.pc,
+                         b.shade_list, b.partial, b.cnt);
+    else if (s->lds_geometry)
+      hipLaunchKernelGGL((k_render_fused<true, false>), dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
                          s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, b.pc,
                          b.shade_list, b.partial, b.cnt);
     else
-      hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
+      hipLaunchKernelGGL((k_render_fused<false, false>), dim3(grid), dim3(kBlock), 0, st, a, s->ds, s->dl,
                          s->mats.ptr, s->node_info.ptr, s->n_materials, s->n_light_tris, b.pc,
                          b.shade_list, b.partial, b.cnt);
   }));
@@ -836,6 +847,7 @@ int rtr_scene_create(const rtr_scene_desc *d, int device, rtr_scene **out) {
   s->ds.pair_second = s->pair_second.ptr;
   s->ds.n_items = (int32_t)flags.n_items;
   s->ds.n_pairs = (int32_t)flags.n_pairs;
+  s->ds.near_prims = flags.far_prims == 0 ? 1 : 0;
   s->lds_geometry = d->n_nodes <= kLdsNodes && d->n_tris <= kLdsTris && d->n_spheres <= kLdsSphs &&
                     info_fits && fits_lds_shade(d->n_materials, d->n_lights, (int)light_tris.size());
   s->n_light_tris = (int)light_tris.size();

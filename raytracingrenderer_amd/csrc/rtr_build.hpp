@@ -40,6 +40,7 @@ struct BuildFlags {
   uint32_t slow_planes;  // != 0: some box plane is outside the division-free test's range
   uint32_t not_nested;   // != 0: some box does not contain its child's box
   uint32_t n_items, n_pairs;  // trace_all2's record table (small scenes)
+  uint32_t far_prims;    // != 0: a vertex coordinate or a sphere's extent beyond 2^20 in magnitude (or not a number)
 };
 
 // The description's arrays in device memory (copies, freed after the build).
@@ -92,15 +93,23 @@ k_build_prims(BuildInput in, BuildOutput out, BuildFlags *flags) {
 
 // primitives as records: {p0, n.x} {p1, n.y} {p2, n.z}; {c, r}
 __global__ void __launch_bounds__(kBuildBlock)
-k_build_geometry(BuildInput in, BuildOutput out) {
+k_build_geometry(BuildInput in, BuildOutput out, BuildFlags *flags) {
   const int t = blockIdx.x * kBuildBlock + threadIdx.x;
+  // |v| <= 2^20, false for a NaN
+  auto near = [](float v) { return fabsf(v) <= 1048576.0f; };
+  bool ok = true;
   if (t < in.n_tris) {
     out.tris[3 * (size_t)t] = make_float4(in.p0[0][t], in.p0[1][t], in.p0[2][t], in.tn[0][t]);
     out.tris[3 * (size_t)t + 1] = make_float4(in.p1[0][t], in.p1[1][t], in.p1[2][t], in.tn[1][t]);
     out.tris[3 * (size_t)t + 2] = make_float4(in.p2[0][t], in.p2[1][t], in.p2[2][t], in.tn[2][t]);
     out.tri_area[t] = in.tri_area[t];
+    for (int a = 0; a < 3; a++) ok = ok && near(in.p0[a][t]) && near(in.p1[a][t]) && near(in.p2[a][t]);
   }
-  if (t < in.n_sphs) out.sphs[t] = make_float4(in.sc[0][t], in.sc[1][t], in.sc[2][t], in.sr[t]);
+  if (t < in.n_sphs) {
+    out.sphs[t] = make_float4(in.sc[0][t], in.sc[1][t], in.sc[2][t], in.sr[t]);
+    for (int a = 0; a < 3; a++) ok = ok && near(fabsf(in.sc[a][t]) + fabsf(in.sr[t]));
+  }
+  if (!ok) flags->far_prims = 1u;
 }
 
 // every node names its children's parent; what is wrong with a node on its own

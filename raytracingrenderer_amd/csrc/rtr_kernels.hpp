@@ -1108,7 +1108,8 @@ RTR_DEV void hit_info(const DeviceScene &sc, const DeviceMaterial *__restrict__ 
 #define RTR_FUSED_WAVES_WALK_MIN 4
 #define RTR_FUSED_WAVES_WALK_MAX 4
 #endif
-template <bool kLds>
+// kBounded (with kLds): the flavour for scenes whose arithmetic cannot overflow (trace_all2).
+template <bool kLds, bool kBounded>
 __global__ void __launch_bounds__(kBlock)
     __attribute__((amdgpu_waves_per_eu(kLds ? RTR_FUSED_WAVES : RTR_FUSED_WAVES_WALK_MIN,
                                        kLds ? RTR_FUSED_WAVES : RTR_FUSED_WAVES_WALK_MAX)))
@@ -1263,7 +1264,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
       const uint64_t table = (uint64_t)cold.items;
       const float4 *items = (const float4 *)(((uint64_t)wave_first((uint32_t)(table >> 32)) << 32) |
                                              wave_first((uint32_t)table));
-      const HitPair hp = trace_all2(sc, items, (int)wave_first((uint32_t)cold.n_items),
+      const HitPair hp = trace_all2<kBounded>(sc, items, (int)wave_first((uint32_t)cold.n_items),
                                     wave_first((uint32_t)cold.n_pairs) != 0u, lds, e.has_shadow, e.has_ext,
                                     pos, e.l, ln, e.w1, wn, ws.merge, clk);
       hs = hp.a;

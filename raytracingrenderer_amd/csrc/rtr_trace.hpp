@@ -51,6 +51,7 @@ struct DeviceScene {
   const float4 *items;
   const float4 *pair_second;
   int32_t n_items, n_pairs;
+  int32_t near_prims;  // 1: every vertex coordinate and every sphere's extent is within 2^20 in magnitude
 };
 
 // Where traversal reads geometry from.  GlobalGeom gathers from HBM through the
@@ -1303,6 +1304,16 @@ struct HitPair {
   int node_a, node_b;  // the leaves' node indices (-1 for a miss)
 };
 
+//
+// kBounded: the scene's planes are in the division-free box test's range, its boxes nested and its
+// primitives within 2^20 of the origin (DeviceScene::fast_planes, nested_boxes, near_prims).  A ray
+// is then either re-traced for its own sake -- an origin component beyond 2^20 or a direction
+// component outside [2^-20, 2] -- or cannot produce an infinite or undefined distance at all:
+// s and the edges are below 2^21, s1 below 2^23, se below 2^46, s2 below 2^43, the numerator of t
+// below 2^66 and t, with |1 / se| <= 2^60 (se_lo), below 2^126; b1 and b2 below 2^106; a sphere's b
+// below 2^25, its discriminant below 2^50.  The sum of distances and the largest |se| are not
+// accumulated for such a scene, and the winners' boxes take the one-box form unconditionally.
+template <bool kBounded>
 RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int n_items, bool has_pairs,
                            const LdsScene &lds, bool valid_a, bool valid_b,
                            V3 o, V3 dir_a, V3 dn_a, V3 dir_b, V3 dn_b, MergeStack &merge, SectionClock &clk) {
@@ -1361,7 +1372,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
     const f32x2 b1 = inv * dot(s1, splat(s));
     const f32x2 b2 = inv * dot(splat(s2), dn);
     const f32x2 w = splat(1.0f) - b1 - b2;
-    t_sum = t_sum + t;
+    if constexpr (!kBounded) t_sum = t_sum + t;
     // !(t < eps || b1 < eps || b2 < eps || w < eps), src/Trangle.cpp:17: a NaN fails no
     // comparison there and is passed over by the minimum here
     const float ma = min_raw(min3_raw(t.x, b1.x, b2.x), w.x);
@@ -1403,7 +1414,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
     const V3x2 s1 = cross(dn, splat(e2));
     const f32x2 se = dot(s1, splat(e1));
     se_lo = min3_abs(se_lo, se.x, se.y);
-    se_hi = max3_abs(se_hi, se.x, se.y);
+    if constexpr (!kBounded) se_hi = max3_abs(se_hi, se.x, se.y);
     const f32x2 inv = f32x2{reciprocal_fast(se.x), reciprocal_fast(se.y)};
     const f32x2 facing = dot(ndir, splat(n));
     const f32x2 thr = f32x2{opaque(facing.x < 0 ? inf : kTriEps), opaque(facing.y < 0 ? inf : kTriEps)};
@@ -1517,7 +1528,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
       const float t1 = div_corrected(n1, a, y);
       const float t2 = div_corrected(n2, a, y);
       const float t = (t2 < 0) ? t1 : t2;
-      tsum = tsum + (act ? t : 0.0f);
+      if constexpr (!kBounded) tsum = tsum + (act ? t : 0.0f);
       // a hit's distance, or NaN: no hit (src/Sphere.cpp:19), or a lane without a mark
       float tt = opaque(!(t1 < kSphEps) ? t : nan);
       tt = opaque(act ? tt : nan);
@@ -1562,7 +1573,7 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
   // that is neither zero nor of magnitude in [2^-20, 2^20]) is re-traced.  Elsewhere: leaf to root,
   // with the IEEE divisions when some lane needs them.
   bool ok_a, ok_b;
-  if (sc.fast_planes != 0 && sc.nested_boxes != 0) {
+  if (kBounded || (sc.fast_planes != 0 && sc.nested_boxes != 0)) {
     // origin: twice the magnitude's bit pattern less one wraps a zero to the top, so the least of
     // the three is at least 2 * bits(2^-20) - 1 unless some component is tiny and not zero
     const uint32_t ox = __float_as_uint(o.x), oy = __float_as_uint(o.y), oz = __float_as_uint(o.z);

@@ -279,6 +279,37 @@ def test_trees_whose_boxes_are_not_nested(rt):
             assert x.shape == y.shape and _rays.same_bits(x, y).all()
 
 
+def test_primitives_beyond_their_boxes(rt):
+    """The reference never checks that a leaf's box holds its primitive.  A triangle with a vertex
+    at 3e30 under boxes clamped into the division-free test's range: planes in range, boxes nested,
+    so only the primitives' own coordinates tell that this scene's arithmetic can overflow (products
+    of such coordinates are infinite).  The fused kernel then has to run the flavour that watches
+    for infinite and undefined distances; hits, images and counters equal the checker's."""
+    spec = default_scene_spec()
+    far = np.array([[100, 100, -100], [3e30, 120, -150], [140, 3e30, -120]], f32)
+    spec["objects"] = spec["objects"] + [("mesh", "white", far, [0, 1, 2])]
+    O = Oracle()
+    so = O.build_scene(spec)
+    O.set_math(so, portable=True)
+    sg = rt.HostScene.from_spec(spec)
+    lo, hi, child, prim = sg.flatten()
+    for k in range(len(prim)):
+        nlo, nhi = np.clip(lo[k], -1000, 1000), np.clip(hi[k], -1000, 1000)
+        sg.set_node_box(k, nlo, nhi)
+        O.set_node_box(so, k, nlo, nhi)
+    nodes, parent, leaves, (fast, nested) = sg.read_tree()
+    assert fast == 1 and nested == 1
+    org, d = _rays.default_batch(O, so, n_interior=30000, prim_step=16)
+    want = so.intersect(org, d)
+    _assert_hits_equal(sg.intersect(org, d), want)
+    assert (want[0] == 19).sum() > 50      # the far triangle is hit, where it crosses the box
+    img, stats = O.render(so, 48, 48, 8, seed=3, chunk_spp=4)
+    for how in MODES:
+        rgb, st = sg.render(48, 48, 8, seed=3, chunk_spp=4, **how)
+        _assert_images_equal(rgb, img)
+        assert st.rays == stats[1] and st.vertices == stats[3]
+
+
 def test_check_connectable(rt, scenes):
     """Scene::checkConnectable on the default scene (all-leaves traversal) and on a scene
     with thousands of primitives (tree walk): same booleans as the checker."""

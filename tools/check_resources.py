@@ -18,8 +18,9 @@ import sys
 
 # kernel-name fragment -> (most SGPR spills allowed, least waves per SIMD, most VGPR spills allowed)
 GATES = {
-    "k_render_fusedILb1E": (8, 4, 0),     # scene staged in LDS (the Cornell box)
-    "k_render_fusedILb0E": (16, 4, 32),   # tree walked in memory
+    "k_render_fusedILb1ELb1E": (8, 4, 0),    # scene staged in LDS, bounded arithmetic (the Cornell box)
+    "k_render_fusedILb1ELb0E": (8, 4, 0),    # scene staged in LDS
+    "k_render_fusedILb0ELb0E": (16, 4, 32),  # tree walked in memory
 }
 
 
