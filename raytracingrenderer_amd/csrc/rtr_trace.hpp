@@ -1311,8 +1311,8 @@ struct HitPair {
 // component outside [2^-20, 2] -- or cannot produce an infinite or undefined distance at all:
 // s and the edges are below 2^21, s1 below 2^23, se below 2^46, s2 below 2^43, the numerator of t
 // below 2^66 and t, with |1 / se| <= 2^60 (se_lo), below 2^126; b1 and b2 below 2^106; a sphere's b
-// below 2^25, its discriminant below 2^50.  The sum of distances and the largest |se| are not
-// accumulated for such a scene, and the winners' boxes take the one-box form unconditionally.
+// below 2^25, its discriminant below 2^51 and the numerators of its roots below 2^26.  The sum of
+// distances, the largest |se|, discriminant and numerator are not accumulated for such a scene, and the winners' boxes take the one-box form unconditionally.
 template <bool kBounded>
 RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int n_items, bool has_pairs,
                            const LdsScene &lds, bool valid_a, bool valid_b,
@@ -1520,10 +1520,10 @@ RTR_DEV HitPair trace_all2(const DeviceScene &sc, const float4 *item_table, int 
       const bool grazing = delta == 0.0f;
       const float ds = opaque(grazing ? 1.0f : delta);
       d_lo = min_raw(d_lo, ds);
-      d_hi = max3_abs(d_hi, ds, ds);
+      if constexpr (!kBounded) d_hi = max3_abs(d_hi, ds, ds);  // (bounded: delta is below 2^51)
       const float sq = opaque(grazing ? delta : sqrt_ranged(ds));
       const float n1 = (-b + sq) / 2, n2 = (-b - sq) / 2;
-      n_hi = max3_abs(n_hi, n1, n2);
+      if constexpr (!kBounded) n_hi = max3_abs(n_hi, n1, n2);  // (bounded: the numerators are below 2^26)
       n_tiny |= opaque((tiny_below(n1, 0x2b800000u) || tiny_below(n2, 0x2b800000u)) ? 1u : 0u);
       const float t1 = div_corrected(n1, a, y);
       const float t2 = div_corrected(n2, a, y);
