@@ -408,11 +408,12 @@ k_tb_swap(BigRange *list, int count, float *key, uint32_t *idx, const uint32_t *
   const int tid = threadIdx.x;
   if (tid == 0) s_range = range_of_tile(list, count, blockIdx.x);
   __syncthreads();
-  const BigRange rg = list[s_range];
-  const int t = blockIdx.x - rg.tile_base, first = rg.f + 1;
-  const int tiles = (rg.l - first + kTile - 1) / kTile;
+  // (other tiles of the range write its K, cl and cr meanwhile: only the fields set when it was queued are read)
+  const int rf = list[s_range].f, rl = list[s_range].l, tile_base = list[s_range].tile_base;
+  const int t = blockIdx.x - tile_base, first = rf + 1;
+  const int tiles = (rl - first + kTile - 1) / kTile;
   uint32_t ucl, ucr;
-  sum_tiles(tile_counts, rg.tile_base, rg.tile_base + tiles, s_sum, ucl, ucr);
+  sum_tiles(tile_counts, tile_base, tile_base + tiles, s_sum, ucl, ucr);
   const int cl = (int)ucl, cr = (int)ucr, m = cl < cr ? cl : cr;
   if (t == 0 && tid == 0) list[s_range].cl = cl, list[s_range].cr = cr;
   for (int e = 0; e < kBigE; e++) {
