@@ -762,6 +762,7 @@ RTR_DEV void shade_vertex(const RenderArgs &a, const Tab &T, V3 pos, V3 N, V3 wi
   // (N is the normalised normal of the hit: its second normalisation takes the short way)
   const V3 ui = kUnitWi ? wi : unit(wi), un = unit_near(N);  // shared by the two evaluations below
   VertexStream rng(a.seed, gpix, k, depth);
+  rng.round_keys = T.philox_keys();
   LightSample ls;
   sample_light(T, rng, ls);
   e.has_shadow = false;
@@ -1129,6 +1130,7 @@ k_render_fused(RenderArgs a, DeviceScene sc, DeviceLights L, const DeviceMateria
     for (int i = tid; i < n_light_tris; i += kBlock) lsh.light_tris[i] = L.light_tris[i];
     for (int i = tid; i < sc.n_tris; i += kBlock) lsh.tri_area[i] = L.tri_area[i];
     for (int i = tid; i < sc.n_nodes; i += kBlock) lsh.node_info[i] = node_info[i];
+    if (tid < 10) lsh.philox_keys[tid] = make_uint2(a.seed + (uint32_t)tid * 0x9E3779B9u, (uint32_t)tid * 0xBB67AE85u);
     __syncthreads();
   }
   typename WaveLds<kLds>::type &ws = wsh[tid >> 6];

@@ -207,8 +207,12 @@ RTR_DEV void sincos_fixed(float x, float &s_out, float &c_out) {
 }
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
+// round_keys (optional): the ten rounds' keys {k0 + r * 0x9E3779B9, k1 + r * 0xBB67AE85} in a table
+// (LDS): the keys are the same for every lane, so computed here they sit in scalar registers, and an
+// exclusive-or with a scalar operand issues at half rate; read from LDS they arrive in vector
+// registers over a pipe the kernel leaves idle.
 RTR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                           uint32_t k1, uint32_t out[4]) {
+                           uint32_t k1, uint32_t out[4], const uint2 *round_keys = nullptr) {
 #ifdef RTR_EXP_CHEAP_RNG  // development switch (a poor generator)
   out[0] = c0 * 0x9E3779B9u + c1 + k0; out[1] = out[0] * 0x85EBCA6Bu + c2; out[2] = out[1] * 0xC2B2AE35u + c3; out[3] = out[2] * 0x27D4EB2Fu + k1;
   out[0] ^= out[3] >> 15; out[1] ^= out[0] >> 13; out[2] ^= out[1] >> 16; out[3] ^= out[2] >> 14;
@@ -222,10 +226,16 @@ RTR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    uint32_t n0, n2;
+    if (round_keys) {
+      const uint2 rk = round_keys[r];
+      n0 = hi1 ^ c1 ^ rk.x, n2 = hi0 ^ c3 ^ rk.y;
+    } else {
+      n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
@@ -241,12 +251,13 @@ struct VertexStream {
   uint32_t w[4];
   int block;
   uint32_t key1;
+  const uint2 *round_keys = nullptr;  // philox4x32_10's table for (seed, key1), if there is one
   RTR_DEV VertexStream(uint32_t se, uint32_t px, uint32_t sa, uint32_t bo, uint32_t k1 = 0u)
       : seed(se), pixel(px), sample(sa), bounce(bo), dim(0), block(-1), key1(k1) {}
   RTR_DEV float next() {
     int b = (int)(dim >> 2);
     if (b != block) {
-      philox4x32_10(pixel, sample, bounce, (uint32_t)b, seed, key1, w);
+      philox4x32_10(pixel, sample, bounce, (uint32_t)b, seed, key1, w, round_keys);
       block = b;
     }
     uint32_t d = dim & 3u;

@@ -36,6 +36,7 @@ struct LdsShade {
   int32_t light_tris[kLdsLightTris];
   float tri_area[kLdsTris];
   int32_t node_info[kLdsNodes];  // leaf nodes: prim id | material << 16 | emissive << 30
+  uint2 philox_keys[10];         // the generator's round keys for (seed, 0): see philox4x32_10
 };
 struct GlobalTables {
   const DeviceScene &sc;
@@ -50,6 +51,7 @@ struct GlobalTables {
   RTR_DEV float4 sph(int row) const { return sc.sphs[row]; }
   RTR_DEV int n_lights() const { return L.n_lights; }
   RTR_DEV float total_area() const { return L.total_area; }
+  RTR_DEV const uint2 *philox_keys() const { return nullptr; }
 };
 struct LdsTables {
   const LdsScene &g;
@@ -65,6 +67,7 @@ struct LdsTables {
   RTR_DEV float4 sph(int row) const { return g.sphs[row]; }
   RTR_DEV int n_lights() const { return nl; }
   RTR_DEV float total_area() const { return area; }
+  RTR_DEV const uint2 *philox_keys() const { return s.philox_keys; }
 };
 __host__ __device__ inline bool fits_lds_shade(int n_materials, int n_lights, int n_light_tris) {
   return n_materials <= kLdsMats && n_lights <= kLdsLights && n_light_tris <= kLdsLightTris;
