@@ -199,11 +199,13 @@ RTR_DEV void sincos_fixed(float x, float &s_out, float &c_out) {
   cp = cp * z + -1.388731625493765e-3f;
   cp = cp * z + 4.166664568298827e-2f;
   float c = 1.0f - 0.5f * z + z * z * cp;
-  int q = k & 3;
-  float ss = (q & 1) ? c : s;
-  float cc = (q & 1) ? s : c;
-  s_out = (q & 2) ? -ss : ss;
-  c_out = (q == 1 || q == 2) ? -cc : cc;
+  // quadrant k & 3: sine and cosine change places in the odd ones; the sine is negated in quadrants
+  // 2 and 3, the cosine in 1 and 2 -- bit 1 of k and of k + 1, moved onto the sign bit (a negation
+  // is a flip of that bit, for zeros and NaNs too)
+  const bool odd = (k & 1) != 0;
+  const float ss = odd ? c : s, cc = odd ? s : c;
+  s_out = __uint_as_float(__float_as_uint(ss) ^ (((uint32_t)k & 2u) << 30));
+  c_out = __uint_as_float(__float_as_uint(cc) ^ (((uint32_t)(k + 1) & 2u) << 30));
 }
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
