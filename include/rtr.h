@@ -200,7 +200,8 @@ int rtr_device_count(int *n);
  * lengths outside the short path's range); the closed-form normalisation of vectors already of
  * unit length on every case of its window; colour / scalar / scalar by reciprocals and one
  * residual correction with the six IEEE divisions on 2^30 colours, zeros of either sign and
- * operands outside its range included.
+ * operands outside its range included; colour / pi by a residual correction with the IEEE quotient for
+ * all 2^32 floats.
  * *mismatches = number of differing results; anything but 0 means this toolchain or
  * device does not reproduce the reference's arithmetic and results are not to be trusted.
  */

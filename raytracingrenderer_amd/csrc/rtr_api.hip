@@ -952,6 +952,7 @@ int rtr_self_test(int device, uint64_t *mismatches) {
   hipError_t e = hipMemset(d_bad, 0, sizeof(*d_bad));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_selftest_reciprocal, dim3(65536), dim3(kBlock), 0, nullptr, d_bad);
+    hipLaunchKernelGGL(k_selftest_div_by_pi, dim3(65536), dim3(kBlock), 0, nullptr, d_bad);
     // every float in [2^-100, 2^100], a quarter of them per launch (the last one takes 2^100 itself)
     const uint32_t lo = (127u - 100u) << 23, total = 200u << 23;
     for (uint32_t done = 0; done < total; done += total / 4) {

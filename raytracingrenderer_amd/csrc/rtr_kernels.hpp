@@ -276,6 +276,25 @@ k_selftest_reciprocal(unsigned long long *__restrict__ mismatches) {
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// div_by_pi against the IEEE quotient x / (float)pi for all 2^32 floats (both signs of zero, the
+// numerators outside its range, infinities and NaNs included): thread t of workgroup b takes the
+// bit patterns b * 65536 + 3 k * 256 + t, three at a time as one colour, so that the lanes of a
+// wave hold neighbouring patterns and the wave's guard is met wherever the range is.
+__global__ void __launch_bounds__(kBlock)
+k_selftest_div_by_pi(unsigned long long *__restrict__ mismatches) {
+  unsigned bad = 0;
+  const float pi = (float)kPi;
+  for (unsigned k = 0; k + 3u <= 258u; k += 3u) {  // (the last colour runs two patterns into the next workgroup's)
+    const uint32_t u = blockIdx.x * 65536u + k * 256u + threadIdx.x;
+    const V3 x = mk(__uint_as_float(u), __uint_as_float(u + 256u), __uint_as_float(u + 512u));
+    const V3 got = div_by_pi(x);
+    const float w[3] = {x.x / pi, x.y / pi, x.z / pi}, g[3] = {got.x, got.y, got.z};
+    for (int c = 0; c < 3; c++)  // any NaN equals any NaN
+      bad += (__float_as_uint(g[c]) != __float_as_uint(w[c]) && !(g[c] != g[c] && w[c] != w[c])) ? 1u : 0u;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // sqrt_ranged against sqrtf for every float in [2^-100, 2^100]: thread i of the launch takes
 // bit pattern lo + i (launched over the 200 * 2^23 patterns of that range).
 __global__ void __launch_bounds__(kBlock)

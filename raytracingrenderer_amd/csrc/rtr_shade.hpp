@@ -112,6 +112,23 @@ RTR_DEV float smith_g(float roughness, V3 N, V3 V, V3 L) {
   return g1 * g2;
 }
 
+// x / MY_PI for the three components of a colour (src/Material.cpp:92): three IEEE divisions by
+// the same constant, by one residual correction each of x * RN(1 / pi) (div_corrected) when, for
+// every lane of the wave, every component is zero or of magnitude in [2^-60, 2^60]; the numerator's
+// sign is put back (a zero of either sign is common).
+RTR_DEV V3 div_by_pi(V3 x) {
+  const float pi = (float)kPi;
+  const uint32_t bx = __float_as_uint(x.x), by = __float_as_uint(x.y), bz = __float_as_uint(x.z);
+  const uint32_t least = min3_u32(bx + bx - 1u, by + by - 1u, bz + bz - 1u);  // a zero wraps to the top
+  const bool bad = least < 2u * 0x21800000u - 1u || !(max3_abs3(x.x, x.y, x.z) <= 1152921504606846976.0f);
+  if (__ballot(bad) == 0) {
+    const float y = 1.0f / pi;  // folded by the compiler: the correctly rounded reciprocal
+    return mk(__builtin_copysignf(div_corrected(x.x, pi, y), x.x), __builtin_copysignf(div_corrected(x.y, pi, y), x.y),
+              __builtin_copysignf(div_corrected(x.z, pi, y), x.z));
+  }
+  return mk(x.x / pi, x.y / pi, x.z / pi);
+}
+
 // Material::eval, src/Material.cpp:66-95.  The reference normalises wi, wo and n
 // again in every branch; ui = unit(wi) and un = unit(n) are passed in so that a
 // vertex which evaluates its material twice forms them once.
@@ -140,7 +157,7 @@ RTR_DEV V3 mat_eval_units(const DeviceMaterial &m, V3 ui, V3 wo, V3 un, V3 &uo) 
       float g = smith_g(rough, un, ui, uo);
       float co = dot(uo, un);
       float ci = dot(ui, un);
-      res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + kd * (1 - kr) / (float)kPi;
+      res = ks * (kr * d * g / 4.0f / maxf(co * ci, 0.0001f)) + div_by_pi(kd * (1 - kr));
     }
   }
   return res;
