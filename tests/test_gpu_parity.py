@@ -437,6 +437,18 @@ def test_render_bit_exact_vs_checker(scenes, W, H, spp, chunk, how):
     assert rgb.mean() > 0.05
 
 
+def test_full_resolution_image_bit_exact(scenes):
+    """The benchmark's image size, 784 x 784, at 48 samples per pixel (about 100 M rays): every pixel
+    and both counters equal to the checker's, fused kernel and wavefront loop.  (The full 1024 spp
+    take the checker a minute on sixteen cores: tools/big_bitexact.py 784 1024 default.)"""
+    O, so, sg = scenes
+    want, stats = O.render(so, 784, 784, 48, seed=3, chunk_spp=8, threads=16)
+    for how in (dict(mode=2), dict(mode=1)):
+        rgb, st = sg.render(784, 784, 48, seed=3, chunk_spp=8, **how)
+        _assert_images_equal(rgb, want)
+        assert st.rays == stats[1] and st.vertices == stats[3]
+
+
 @pytest.mark.parametrize("how", MODES, ids=MODE_IDS)
 def test_render_edge_parameters(rt, scenes, how):
     """One pixel, one sample; a chunk longer than the sample count; paths cut at the first
